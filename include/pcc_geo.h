@@ -1,0 +1,164 @@
+/*
+ * pcc_geo.h -- C ABI of libpcc_geo_hip.so, the MI355X (gfx950) implementation of the
+ * 64^3-voxel-block encode+decode hot path of mauriceqch/pcc_geo_cnn_v2.
+ *
+ * The reference has NO native/FFI interface for this path: its operators are TensorFlow-1.15 /
+ * tensorflow-compression-1.3 ops invoked from Python.  Each entry point below
+ * therefore names the reference call site (file:line under /root/reference) whose third-party op it
+ * replaces; INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no torch types; every function returns 0 on success, <0 on error
+ *     (pcc_last_error() returns the message of the calling thread's last failure);
+ *   - device buffers are owned by the caller (PyTorch-ROCm tensors' data_ptr()); the library
+ *     allocates nothing persistent except the context it frees in pcc_ctx_destroy;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are stream-ordered,
+ *     asynchronous, and not re-entrant on one context;
+ *   - activations: NDHWC float32, (D,H,W) = (x,y,z) as in src/model_types.py:108-114;
+ *     forward kernels (kd,kh,kw,Cin,Cout), transposed kernels (kd,kh,kw,Cout,Cin)  [Keras layouts];
+ *   - all convolutions are TF padding='same' (asymmetric, extra element on the high side).
+ */
+#ifndef PCC_GEO_H
+#define PCC_GEO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCC_ABI_VERSION 1
+
+/* ---- errors / context ------------------------------------------------------------------ */
+#define PCC_OK 0
+#define PCC_ERR_ARG (-1)     /* bad argument / unsupported shape                                   */
+#define PCC_ERR_HIP (-2)     /* a HIP runtime call failed                                          */
+#define PCC_ERR_NOGPU (-3)   /* no gfx950 device visible                                           */
+#define PCC_ERR_SPACE (-4)   /* output buffer too small                                            */
+#define PCC_ERR_CORRUPT (-5) /* range decoder ran past a corrupt stream                            */
+
+typedef struct pcc_ctx pcc_ctx;
+
+int pcc_abi_version(void);
+const char* pcc_last_error(void);
+/* Replaces tf.Session creation (src/compress_octree.py:84-92).  One context per (process, GPU). */
+int pcc_ctx_create(int device, pcc_ctx** out);
+int pcc_ctx_destroy(pcc_ctx* ctx);
+/* Number of compute units of the context's device (256 on MI355X); <0 on error. */
+int pcc_ctx_num_cu(pcc_ctx* ctx);
+
+/* ---- 3-D convolution / transposed convolution -------------------------------------------
+ * Replaces the TF ops behind keras Conv3D / Conv3DTranspose (+BiasAdd, Relu, AddV2) at
+ * src/model_transforms.py:45-47,56-58,67-69,78-80,93,107,121,135,144-146,155-157 and the residual
+ * add of ResidualLayer.call (src/model_transforms.py:30-36).
+ * out = [clip01]( relu?(conv(in) + bias?) + residual? )                                        */
+#define PCC_CONV_BIAS 1
+#define PCC_CONV_RELU 2
+#define PCC_CONV_ADD 4     /* add `residual` AFTER the activation (ResidualLayer 'add' mode)      */
+#define PCC_CONV_CLIP01 8  /* np.clip(x_hat,0,1) fused (src/model_types.py:202), encoder flavour  */
+
+#define PCC_IMPL_AUTO 0    /* MFMA implicit-GEMM when the shape is covered, else generic          */
+#define PCC_IMPL_GENERIC 1 /* direct convolution, any shape (reference-order fp32 FMA chain)      */
+#define PCC_IMPL_MFMA 2    /* force the MFMA path; PCC_ERR_ARG if the shape is not covered        */
+
+typedef struct {
+    int32_t N, D, H, W;    /* input batch and spatial size                                       */
+    int32_t Cin, Cout;
+    int32_t k;             /* cubic kernel size: 3, 5 or 9 on the fast path, any odd k generic    */
+    int32_t stride;        /* 1 or 2                                                              */
+    int32_t transposed;    /* 0 = Conv3D, 1 = Conv3DTranspose                                     */
+    int32_t flags;         /* PCC_CONV_*                                                          */
+    int32_t impl;          /* PCC_IMPL_*                                                          */
+    int32_t out_cstride;   /* channel stride of `out` (>= Cout); 0 means Cout.  With out_coffset  */
+    int32_t out_coffset;   /* it implements ResidualLayer 'concat' mode (model_transforms.py:38). */
+} pcc_conv_desc;
+
+/* Output spatial size for a descriptor (ceil(n/s) forward, n*s transposed). */
+int pcc_conv_out_dims(const pcc_conv_desc* d, int32_t* OD, int32_t* OH, int32_t* OW);
+/* Returns 1 if the MFMA path covers the descriptor, 0 otherwise. */
+int pcc_conv_mfma_supported(const pcc_conv_desc* d);
+/* Size in floats of the MFMA-fragment-ordered weight image (0 if the MFMA path does not apply). */
+size_t pcc_conv_packed_floats(const pcc_conv_desc* d);
+/* HOST-side repack of a Keras-layout kernel into MFMA fragment order (done once at model load,
+ * replaces saver.restore's variable placement, src/compress_octree.py:90-92). */
+int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w_keras_host, float* packed_host);
+/* `w` (device, Keras layout) is used by the generic path, `w_packed` (device, may be NULL) by the
+ * MFMA path; `bias`/`residual` may be NULL when the matching flag is clear.  `residual` has the
+ * shape of `out` with channel stride Cout. */
+int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w,
+               const float* w_packed, const float* bias, const float* residual, float* out,
+               void* stream);
+
+/* ---- entropy-model element-wise kernels -------------------------------------------------
+ * Quantisation of tfc.EntropyBottleneck / tfc.GaussianConditional `_quantize`
+ * (call sites src/model_types.py:291,382,386): mode 0 = floor(v + (0.5 - median_c)) [tfc 1.3],
+ * mode 1 = round-half-even(v - median_c).  Channel of element i is i % C (channels-last).
+ * medians/sym/deq may be NULL.  deq = float(sym) + median.                                      */
+#define PCC_ROUND_FLOOR_HALF 0
+#define PCC_ROUND_HALF_EVEN 1
+int pcc_quantize(pcc_ctx* ctx, const float* v, const float* medians, int32_t* sym, float* deq,
+                 size_t n, int32_t C, int32_t mode, void* stream);
+/* deq[i] = float(sym[i]) + medians[i % C]  (tfc `_dequantize`, decoder side). */
+int pcc_dequantize(pcc_ctx* ctx, const int32_t* sym, const float* medians, float* deq, size_t n,
+                   int32_t C, void* stream);
+/* Scale -> CDF-table index, src/utils/patch_gaussian_conditional.py:57-58,104-116: sigma is
+ * lower-bounded at table[0]; idx = (L-1) - #{j < L-1 : sigma <= table[j]}.  Deterministic. */
+int pcc_scale_to_index(pcc_ctx* ctx, const float* sigma, const float* table, int32_t L,
+                       int32_t* idx, size_t n, void* stream);
+
+/* ---- occupancy thresholding + order-preserving compaction ------------------------------
+ * Replaces `np.argwhere(x_hat > thresholds[t]).astype(float32)` (src/model_types.py:209,233-234,
+ * src/model_opt.py:12,29).  x: B blocks of D*H*W float32; thr[b] is the float32 threshold of
+ * block b (device array); clip!=0 applies np.clip(x,0,1) first (encoder, model_types.py:202).
+ * xyz: B * cap * 3 float32, block b's points at xyz + b*cap*3 in C order (x slowest, z fastest),
+ * counts[b] = number of points of block b (may exceed cap: then only the first cap are written).
+ * `scratch` must hold B * ceil(D*H*W/4096) int32.  Bit-exact with the numpy expression.         */
+int pcc_threshold_compact(pcc_ctx* ctx, const float* x, int32_t B, int32_t D, int32_t H,
+                          int32_t W, const float* thr, int32_t clip, float* xyz, int32_t* counts,
+                          int64_t cap, int32_t* scratch, void* stream);
+size_t pcc_threshold_scratch_ints(int32_t B, int32_t D, int32_t H, int32_t W);
+
+/* sparse_to_dense (src/model_types.py:108-114): scatter ones.  pts: int32 (npts,3) local block
+ * coordinates, block_of[i] = destination block; dense must be zero-filled B*D*H*W float32.       */
+int pcc_voxelize(pcc_ctx* ctx, const int32_t* pts, const int32_t* block_of, int64_t npts,
+                 int32_t B, int32_t D, int32_t H, int32_t W, float* dense, void* stream);
+
+/* ---- focal loss (src/utils/focal_loss.py:5-12) ------------------------------------------
+ * Deterministic two-stage reduction (wavefront DPP/shuffle tree, fixed block order); result is a
+ * single float32 written to out[0] (device).  `scratch` must hold pcc_focal_scratch_floats().   */
+int pcc_focal_loss(pcc_ctx* ctx, const float* y_true, const float* y_pred, size_t n, float gamma,
+                   float alpha, float* out, float* scratch, void* stream);
+size_t pcc_focal_scratch_floats(void);
+
+/* ---- range coder (HOST) ----------------------------------------------------------------
+ * Replaces tfc's C++ ops range_coding_ops.unbounded_index_range_encode/decode
+ * (src/utils/patch_gaussian_conditional.py:27-31; src/model_types.py:291-292,382-387,404-407),
+ * which the reference also runs on the CPU (patch_gaussian_conditional.py:105-106).
+ * Streams are independent (one per block and per string); they are coded on `n_threads` host
+ * threads (0 = hardware concurrency).
+ *   data[s], index[s] : n[s] int32 symbols / CDF-row indices of stream s (host pointers);
+ *   index[s] == NULL  : row = i % index_mod (EntropyBottleneck: per-channel tables);
+ *   cdf               : (rows, cdf_stride) int32, row r valid for cdf_size[r] entries;
+ *   offset[r]         : smallest in-table value of row r.                                        */
+typedef struct {
+    const int32_t* cdf;
+    const int32_t* cdf_size;
+    const int32_t* offset;
+    int32_t rows, cdf_stride, precision, overflow_width;
+} pcc_cdf_table;
+
+int pcc_range_encode_batch(const pcc_cdf_table* t, int32_t n_streams, const int32_t* const* data,
+                           const int32_t* const* index, int32_t index_mod, const size_t* n,
+                           uint8_t* const* out, const size_t* cap, size_t* out_len,
+                           int32_t n_threads);
+int pcc_range_decode_batch(const pcc_cdf_table* t, int32_t n_streams, const uint8_t* const* str,
+                           const size_t* str_len, const int32_t* const* index, int32_t index_mod,
+                           const size_t* n, int32_t* const* out, int32_t n_threads);
+/* tfc `pmf_to_quantized_cdf` (src/utils/patch_gaussian_conditional.py:87-89): pmf[n] -> cdf[n+1]. */
+int pcc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, int32_t* cdf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCC_GEO_H */

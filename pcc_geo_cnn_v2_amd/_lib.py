@@ -1,0 +1,92 @@
+"""ctypes binding of libpcc_geo_hip.so (the C ABI declared in include/pcc_geo.h).
+
+The library is built in-tree by `make -C pcc_geo_cnn_v2_amd/csrc` (see __graft_entry__.build()).
+There is NO CPU fallback: if the shared object is missing, or no gfx950 device is visible when a
+context is requested, the product path raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpcc_geo_hip.so')
+
+PCC_CONV_BIAS, PCC_CONV_RELU, PCC_CONV_ADD, PCC_CONV_CLIP01 = 1, 2, 4, 8
+PCC_IMPL_AUTO, PCC_IMPL_GENERIC, PCC_IMPL_MFMA = 0, 1, 2
+PCC_ROUND_FLOOR_HALF, PCC_ROUND_HALF_EVEN = 0, 1
+
+EXPORTS = [
+    'pcc_abi_version', 'pcc_last_error', 'pcc_ctx_create', 'pcc_ctx_destroy', 'pcc_ctx_num_cu',
+    'pcc_conv_out_dims', 'pcc_conv_mfma_supported', 'pcc_conv_packed_floats', 'pcc_conv_pack_weights',
+    'pcc_conv3d', 'pcc_quantize', 'pcc_dequantize', 'pcc_scale_to_index', 'pcc_threshold_compact',
+    'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
+    'pcc_range_encode_batch', 'pcc_range_decode_batch', 'pcc_pmf_to_quantized_cdf',
+]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('N', 'D', 'H', 'W', 'Cin', 'Cout', 'k', 'stride', 'transposed',
+                                         'flags', 'impl', 'out_cstride', 'out_coffset')]
+
+
+class CdfTable(C.Structure):
+    _fields_ = [('cdf', C.POINTER(C.c_int32)), ('cdf_size', C.POINTER(C.c_int32)), ('offset', C.POINTER(C.c_int32)),
+                ('rows', C.c_int32), ('cdf_stride', C.c_int32), ('precision', C.c_int32),
+                ('overflow_width', C.c_int32)]
+
+
+class PccError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (loudly failing if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PccError(f'{LIB_PATH} is missing: build it with `make -C pcc_geo_cnn_v2_amd/csrc` '
+                       '(python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    L.pcc_abi_version.restype = C.c_int
+    L.pcc_last_error.restype = C.c_char_p
+    L.pcc_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.pcc_ctx_destroy.argtypes = [vp]
+    L.pcc_ctx_num_cu.argtypes = [vp]
+    L.pcc_conv_out_dims.argtypes = [C.POINTER(ConvDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.pcc_conv_mfma_supported.argtypes = [C.POINTER(ConvDesc)]
+    L.pcc_conv_packed_floats.argtypes = [C.POINTER(ConvDesc)]
+    L.pcc_conv_packed_floats.restype = sz
+    L.pcc_conv_pack_weights.argtypes = [C.POINTER(ConvDesc), vp, vp]
+    L.pcc_conv3d.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    L.pcc_quantize.argtypes = [vp, vp, vp, vp, vp, sz, i32, i32, vp]
+    L.pcc_dequantize.argtypes = [vp, vp, vp, vp, sz, i32, vp]
+    L.pcc_scale_to_index.argtypes = [vp, vp, vp, i32, vp, sz, vp]
+    L.pcc_threshold_compact.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, C.c_int64, vp, vp]
+    L.pcc_threshold_scratch_ints.argtypes = [i32, i32, i32, i32]
+    L.pcc_threshold_scratch_ints.restype = sz
+    L.pcc_voxelize.argtypes = [vp, vp, vp, C.c_int64, i32, i32, i32, i32, vp, vp]
+    L.pcc_focal_loss.argtypes = [vp, vp, vp, sz, C.c_float, C.c_float, vp, vp, vp]
+    L.pcc_focal_scratch_floats.restype = sz
+    L.pcc_range_encode_batch.argtypes = [C.POINTER(CdfTable), i32, vp, vp, i32, vp, vp, vp, vp, i32]
+    L.pcc_range_decode_batch.argtypes = [C.POINTER(CdfTable), i32, vp, vp, vp, i32, vp, vp, i32]
+    L.pcc_pmf_to_quantized_cdf.argtypes = [vp, i32, i32, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ('pcc_abi_version',):
+            pass
+    _lib = L
+    return L
+
+
+def check(rc, what=''):
+    """Map a negative status to the exception classes the reference raises at the same spot."""
+    if rc is not None and rc < 0:
+        msg = lib().pcc_last_error().decode('utf-8', 'replace')
+        if rc == -1:
+            raise AssertionError(f'{what}: {msg}')
+        raise PccError(f'{what}: {msg} (status {rc})')
+    return rc

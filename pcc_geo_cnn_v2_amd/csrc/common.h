@@ -1,0 +1,49 @@
+// Internal helpers shared by the translation units of libpcc_geo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/pcc_geo.h"
+
+struct pcc_ctx {
+    int device;
+    int num_cu;
+    hipDeviceProp_t prop;
+};
+
+void pcc_set_error(const char* fmt, ...);
+
+#define PCC_API extern "C" __attribute__((visibility("default")))
+
+#define PCC_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            pcc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                          __LINE__);                                                          \
+            return PCC_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define PCC_REQUIRE(cond, ...)        \
+    do {                              \
+        if (!(cond)) {                \
+            pcc_set_error(__VA_ARGS__); \
+            return PCC_ERR_ARG;       \
+        }                             \
+    } while (0)
+
+// TF `SAME` geometry (forward conv): out = ceil(n/s), pad_low = max((out-1)s + k - n, 0) / 2.
+__host__ __device__ inline int pcc_same_out(int n, int s) { return (n + s - 1) / s; }
+__host__ __device__ inline int pcc_same_pad_low(int n, int k, int s) {
+    int tot = (pcc_same_out(n, s) - 1) * s + k - n;
+    return tot > 0 ? tot / 2 : 0;
+}
+
+// entry points implemented per translation unit
+int pcc_conv3d_generic(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w,
+                       const float* bias, const float* residual, float* out, hipStream_t st);
+int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed,
+                    const float* bias, const float* residual, float* out, hipStream_t st);

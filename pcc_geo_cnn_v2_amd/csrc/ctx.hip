@@ -1,0 +1,89 @@
+// Context, error reporting and the conv dispatcher of libpcc_geo_hip.so.
+#include <cstring>
+#include <new>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void pcc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+PCC_API int pcc_abi_version(void) { return PCC_ABI_VERSION; }
+PCC_API const char* pcc_last_error(void) { return g_err; }
+
+PCC_API int pcc_ctx_create(int device, pcc_ctx** out) {
+    PCC_REQUIRE(out != nullptr, "pcc_ctx_create: out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        pcc_set_error("pcc_ctx_create: no HIP device visible");
+        return PCC_ERR_NOGPU;
+    }
+    PCC_REQUIRE(device >= 0 && device < n, "pcc_ctx_create: device %d out of range [0,%d)", device, n);
+    pcc_ctx* c = new (std::nothrow) pcc_ctx();
+    PCC_REQUIRE(c != nullptr, "pcc_ctx_create: out of memory");
+    c->device = device;
+    hipError_t e = hipGetDeviceProperties(&c->prop, device);
+    if (e != hipSuccess) {
+        delete c;
+        pcc_set_error("hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        return PCC_ERR_HIP;
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        pcc_set_error("pcc_ctx_create: device %d is %s, this library is built for gfx950 only", device,
+                      c->prop.gcnArchName);
+        delete c;
+        return PCC_ERR_NOGPU;
+    }
+    c->num_cu = c->prop.multiProcessorCount;
+    *out = c;
+    return PCC_OK;
+}
+
+PCC_API int pcc_ctx_destroy(pcc_ctx* ctx) {
+    delete ctx;
+    return PCC_OK;
+}
+
+PCC_API int pcc_ctx_num_cu(pcc_ctx* ctx) {
+    PCC_REQUIRE(ctx != nullptr, "pcc_ctx_num_cu: ctx is NULL");
+    return ctx->num_cu;
+}
+
+PCC_API int pcc_conv_out_dims(const pcc_conv_desc* d, int32_t* OD, int32_t* OH, int32_t* OW) {
+    PCC_REQUIRE(d && OD && OH && OW, "pcc_conv_out_dims: NULL argument");
+    PCC_REQUIRE(d->stride >= 1, "pcc_conv_out_dims: stride must be >= 1");
+    if (d->transposed) {
+        *OD = d->D * d->stride; *OH = d->H * d->stride; *OW = d->W * d->stride;
+    } else {
+        *OD = pcc_same_out(d->D, d->stride); *OH = pcc_same_out(d->H, d->stride); *OW = pcc_same_out(d->W, d->stride);
+    }
+    return PCC_OK;
+}
+
+PCC_API int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w,
+                       const float* w_packed, const float* bias, const float* residual, float* out,
+                       void* stream) {
+    PCC_REQUIRE(ctx && d && in && out, "pcc_conv3d: NULL argument");
+    PCC_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0,
+                "pcc_conv3d: non-positive dimension");
+    PCC_REQUIRE(d->k >= 1 && (d->stride == 1 || d->stride == 2), "pcc_conv3d: unsupported k/stride");
+    PCC_REQUIRE(!(d->flags & PCC_CONV_BIAS) || bias, "pcc_conv3d: PCC_CONV_BIAS set but bias is NULL");
+    PCC_REQUIRE(!(d->flags & PCC_CONV_ADD) || residual, "pcc_conv3d: PCC_CONV_ADD set but residual is NULL");
+    PCC_REQUIRE(d->out_cstride == 0 || d->out_cstride >= d->Cout + d->out_coffset,
+                "pcc_conv3d: out_cstride too small");
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast_ok = w_packed != nullptr && pcc_conv_mfma_supported(d) == 1;
+    if (d->impl == PCC_IMPL_MFMA) {
+        PCC_REQUIRE(fast_ok, "pcc_conv3d: PCC_IMPL_MFMA requested but shape not covered or w_packed NULL");
+        return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
+    }
+    if (d->impl == PCC_IMPL_AUTO && fast_ok) return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
+    PCC_REQUIRE(w != nullptr, "pcc_conv3d: generic path needs the Keras-layout weights `w`");
+    return pcc_conv3d_generic(ctx, d, in, w, bias, residual, out, st);
+}

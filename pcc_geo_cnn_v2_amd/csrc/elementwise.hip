@@ -1,0 +1,311 @@
+// HBM-bound element-wise / reduction / compaction kernels of the codec path (gfx950).
+//   quantise, dequantise, scale->index, voxelise, threshold + order-preserving compaction,
+//   focal-loss reduction.  All are deterministic (fixed reduction order, no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__host__ inline unsigned grid_for(size_t n, int per_thread, int num_cu) {
+    size_t blocks = (n + (size_t)kThreads * per_thread - 1) / ((size_t)kThreads * per_thread);
+    const size_t cap = (size_t)num_cu * 8;  // grid-stride beyond 8 blocks/CU
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// ---- quantise -----------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_quantize(const float* __restrict__ v, const float* __restrict__ med,
+                                                       int32_t* __restrict__ sym, float* __restrict__ deq,
+                                                       size_t n, int C, int mode) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float m = med ? med[i % (size_t)C] : 0.f;
+        float q;
+        if (mode == PCC_ROUND_FLOOR_HALF) {
+            const float hm = 0.5f - m;  // tfc 1.3: floor(inputs + (half - medians))
+            q = floorf(v[i] + hm);
+        } else {
+            q = rintf(v[i] - m);        // half to even
+        }
+        if (sym) sym[i] = (int32_t)q;
+        if (deq) deq[i] = q + m;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) k_dequantize(const int32_t* __restrict__ sym, const float* __restrict__ med,
+                                                         float* __restrict__ deq, size_t n, int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float m = med ? med[i % (size_t)C] : 0.f;
+        deq[i] = (float)sym[i] + m;
+    }
+}
+
+// ---- scale -> index ------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_scale_index(const float* __restrict__ sigma, const float* __restrict__ table,
+                                                          int L, int32_t* __restrict__ idx, size_t n) {
+    __shared__ float tab[256];
+    for (int j = threadIdx.x; j < L; j += blockDim.x) tab[j] = table[j];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = sigma[i];
+        if (!(s >= tab[0])) s = tab[0];
+        int id = L - 1;
+        for (int j = 0; j < L - 1; ++j) id -= (s <= tab[j]) ? 1 : 0;
+        idx[i] = id;
+    }
+}
+
+// ---- voxelise ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_voxelize(const int32_t* __restrict__ pts, const int32_t* __restrict__ block_of,
+                                                       long long npts, int B, int D, int H, int W,
+                                                       float* __restrict__ dense) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
+        const int x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        const int b = block_of ? block_of[i] : 0;
+        if (b < 0 || b >= B || x < 0 || x >= D || y < 0 || y >= H || z < 0 || z >= W) continue;
+        dense[(((size_t)b * D + x) * H + y) * W + z] = 1.0f;
+    }
+}
+
+// ---- wave / block primitives ---------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one int per thread over a 256-thread block; returns exclusive prefix, *total
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* lds4) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v, lane);
+    __syncthreads();  // lds4 reuse guard
+    if (lane == 63) lds4[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int wv = 0; wv < kThreads / 64; ++wv) {
+        const int s = lds4[wv];
+        if (wv < wave) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// ---- threshold + compaction ----------------------------------------------------------------
+constexpr int kChunk = 4096;  // voxels per workgroup (4 passes of 256 threads x 4 voxels)
+
+__device__ __forceinline__ void load4(const float* __restrict__ xb, size_t idx, size_t nvox, bool vec, float (&v)[4]) {
+    if (vec && idx + 3 < nvox) {
+        const float4 t = *reinterpret_cast<const float4*>(xb + idx);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (idx + e < nvox) ? xb[idx + e] : -INFINITY;
+    }
+}
+
+__device__ __forceinline__ bool hit(float v, float thr, int clip) {
+    if (clip) v = fminf(fmaxf(v, 0.f), 1.f);
+    return v > thr;  // float32 compare (numpy 1.18 value-based casting of the float64 threshold)
+}
+
+__global__ void __launch_bounds__(kThreads) k_thr_count(const float* __restrict__ x, const float* __restrict__ thr,
+                                                        int clip, size_t nvox, int chunks, int32_t* __restrict__ chunk_cnt) {
+    __shared__ int lds4[4];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const float* xb = x + (size_t)b * nvox;
+    const bool vec = (nvox % 4) == 0;
+    const float t = thr[b];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t idx = (size_t)c * kChunk + ((size_t)j * kThreads + threadIdx.x) * 4;
+        float v[4];
+        load4(xb, idx, nvox, vec, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cnt += hit(v[e], t, clip) ? 1 : 0;
+    }
+    int total;
+    block_excl_scan(cnt, &total, lds4);
+    if (threadIdx.x == 0) chunk_cnt[(size_t)b * chunks + c] = total;
+}
+
+__global__ void __launch_bounds__(kThreads) k_thr_write(const float* __restrict__ x, const float* __restrict__ thr,
+                                                        int clip, size_t nvox, int chunks, int H, int W,
+                                                        const int32_t* __restrict__ chunk_cnt, float* __restrict__ xyz,
+                                                        int32_t* __restrict__ counts, long long cap) {
+    __shared__ int lds4[4];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const float* xb = x + (size_t)b * nvox;
+    const bool vec = (nvox % 4) == 0;
+    const float t = thr[b];
+    // offset of this chunk = sum of the counts of the preceding chunks of the same block
+    int part = 0;
+    for (int j = threadIdx.x; j < c; j += kThreads) part += chunk_cnt[(size_t)b * chunks + j];
+    int offset;
+    block_excl_scan(part, &offset, lds4);
+    float* ob = xyz + (size_t)b * (size_t)cap * 3;
+    const int HW = H * W;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const size_t idx = (size_t)c * kChunk + ((size_t)j * kThreads + threadIdx.x) * 4;
+        float v[4];
+        load4(xb, idx, nvox, vec, v);
+        bool h[4];
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = hit(v[e], t, clip); cnt += h[e] ? 1 : 0; }
+        int total;
+        int pos = offset + block_excl_scan(cnt, &total, lds4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (h[e]) {
+                if (pos < cap) {
+                    const size_t vi = idx + e;
+                    const int d = (int)(vi / HW);
+                    const int r = (int)(vi - (size_t)d * HW);
+                    ob[(size_t)pos * 3 + 0] = (float)d;
+                    ob[(size_t)pos * 3 + 1] = (float)(r / W);
+                    ob[(size_t)pos * 3 + 2] = (float)(r % W);
+                }
+                ++pos;
+            }
+        }
+        offset += total;
+    }
+    if (c == chunks - 1 && threadIdx.x == 0) counts[b] = offset;
+}
+
+// ---- focal loss ----------------------------------------------------------------------------
+constexpr int kFocalBlocks = 1024;  // fixed: the reduction tree is identical on every device
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);  // butterfly: same value, same order in all lanes
+    return v;
+}
+
+__global__ void __launch_bounds__(kThreads) k_focal_partial(const float* __restrict__ yt, const float* __restrict__ yp,
+                                                            size_t n, float gamma, float alpha, float* __restrict__ partial) {
+    __shared__ float lds[kThreads / 64];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = yt[i], p = yp[i];
+        float pt1 = (t == 1.f) ? p : 1.f;
+        float pt0 = (t == 0.f) ? p : 0.f;
+        pt1 = fminf(fmaxf(pt1, 1e-3f), .999f);
+        pt0 = fminf(fmaxf(pt0, 1e-3f), .999f);
+        s += alpha * powf(1.f - pt1, gamma) * logf(pt1) + (1.f - alpha) * powf(pt0, gamma) * logf(1.f - pt0);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int wv = 0; wv < kThreads / 64; ++wv) tot += lds[wv];
+        partial[blockIdx.x] = tot;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) k_focal_final(const float* __restrict__ partial, int nparts, float* __restrict__ out) {
+    __shared__ float lds[kThreads / 64];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += kThreads) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int wv = 0; wv < kThreads / 64; ++wv) tot += lds[wv];
+        out[0] = -tot;
+    }
+}
+
+}  // namespace
+
+PCC_API int pcc_quantize(pcc_ctx* ctx, const float* v, const float* medians, int32_t* sym, float* deq, size_t n,
+                         int32_t C, int32_t mode, void* stream) {
+    PCC_REQUIRE(ctx && v && (sym || deq), "pcc_quantize: NULL argument");
+    PCC_REQUIRE(C > 0 && (mode == PCC_ROUND_FLOOR_HALF || mode == PCC_ROUND_HALF_EVEN), "pcc_quantize: bad C/mode");
+    if (n == 0) return PCC_OK;
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_quantize, dim3(grid_for(n, 4, ctx->num_cu)), dim3(kThreads), 0, (hipStream_t)stream, v, medians,
+                       sym, deq, n, C, mode);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+PCC_API int pcc_dequantize(pcc_ctx* ctx, const int32_t* sym, const float* medians, float* deq, size_t n, int32_t C,
+                           void* stream) {
+    PCC_REQUIRE(ctx && sym && deq && C > 0, "pcc_dequantize: bad argument");
+    if (n == 0) return PCC_OK;
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_dequantize, dim3(grid_for(n, 4, ctx->num_cu)), dim3(kThreads), 0, (hipStream_t)stream, sym,
+                       medians, deq, n, C);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+PCC_API int pcc_scale_to_index(pcc_ctx* ctx, const float* sigma, const float* table, int32_t L, int32_t* idx, size_t n,
+                               void* stream) {
+    PCC_REQUIRE(ctx && sigma && table && idx, "pcc_scale_to_index: NULL argument");
+    PCC_REQUIRE(L >= 1 && L <= 256, "pcc_scale_to_index: table length %d not in [1,256]", L);
+    if (n == 0) return PCC_OK;
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_scale_index, dim3(grid_for(n, 4, ctx->num_cu)), dim3(kThreads), 0, (hipStream_t)stream, sigma,
+                       table, L, idx, n);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+PCC_API int pcc_voxelize(pcc_ctx* ctx, const int32_t* pts, const int32_t* block_of, int64_t npts, int32_t B, int32_t D,
+                         int32_t H, int32_t W, float* dense, void* stream) {
+    PCC_REQUIRE(ctx && dense && (pts || npts == 0), "pcc_voxelize: NULL argument");
+    PCC_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && npts >= 0, "pcc_voxelize: bad dimension");
+    if (npts == 0) return PCC_OK;
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_voxelize, dim3(grid_for((size_t)npts, 1, ctx->num_cu)), dim3(kThreads), 0, (hipStream_t)stream,
+                       pts, block_of, (long long)npts, B, D, H, W, dense);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+PCC_API size_t pcc_threshold_scratch_ints(int32_t B, int32_t D, int32_t H, int32_t W) {
+    const size_t nvox = (size_t)D * H * W;
+    return (size_t)B * ((nvox + kChunk - 1) / kChunk);
+}
+
+PCC_API int pcc_threshold_compact(pcc_ctx* ctx, const float* x, int32_t B, int32_t D, int32_t H, int32_t W,
+                                  const float* thr, int32_t clip, float* xyz, int32_t* counts, int64_t cap,
+                                  int32_t* scratch, void* stream) {
+    PCC_REQUIRE(ctx && x && thr && xyz && counts && scratch, "pcc_threshold_compact: NULL argument");
+    PCC_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cap >= 0, "pcc_threshold_compact: bad dimension");
+    PCC_REQUIRE(B <= 65535, "pcc_threshold_compact: at most 65535 blocks per call");
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    const size_t nvox = (size_t)D * H * W;
+    const int chunks = (int)((nvox + kChunk - 1) / kChunk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_thr_count, dim3(chunks, B), dim3(kThreads), 0, st, x, thr, clip, nvox, chunks, scratch);
+    hipLaunchKernelGGL(k_thr_write, dim3(chunks, B), dim3(kThreads), 0, st, x, thr, clip, nvox, chunks, H, W, scratch,
+                       xyz, counts, (long long)cap);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+PCC_API size_t pcc_focal_scratch_floats(void) { return kFocalBlocks; }
+
+PCC_API int pcc_focal_loss(pcc_ctx* ctx, const float* y_true, const float* y_pred, size_t n, float gamma, float alpha,
+                           float* out, float* scratch, void* stream) {
+    PCC_REQUIRE(ctx && y_true && y_pred && out && scratch, "pcc_focal_loss: NULL argument");
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_focal_partial, dim3(kFocalBlocks), dim3(kThreads), 0, st, y_true, y_pred, n, gamma, alpha, scratch);
+    hipLaunchKernelGGL(k_focal_final, dim3(1), dim3(kThreads), 0, st, scratch, kFocalBlocks, out);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}

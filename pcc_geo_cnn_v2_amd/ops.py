@@ -1,0 +1,251 @@
+"""Thin torch-facing wrappers over the C ABI (include/pcc_geo.h).
+
+PyTorch-ROCm is plumbing only: it owns device memory (tensors) and streams; every operator below is
+a hand-written HIP kernel (or the host range coder) inside libpcc_geo_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One per (process, GPU).  Replaces the tf.Session of src/compress_octree.py:84-92."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise L.PccError('no ROCm device visible to PyTorch: the MI355X path cannot run (no CPU fallback)')
+        self.device = torch.device('cuda', device)
+        h = C.c_void_p()
+        L.check(L.lib().pcc_ctx_create(device, C.byref(h)), 'pcc_ctx_create')
+        self.handle = h
+        self.num_cu = L.lib().pcc_ctx_num_cu(h)
+
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if self.handle is not None:
+            L.lib().pcc_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ConvLayer:
+    """Weights of one Conv3D / Conv3DTranspose (Keras layouts) + their device images."""
+
+    def __init__(self, kernel, bias, stride, transposed, relu):
+        kernel = np.ascontiguousarray(kernel, np.float32)
+        self.k = int(kernel.shape[0])
+        assert kernel.shape[:3] == (self.k,) * 3
+        self.transposed = bool(transposed)
+        if transposed:
+            self.cout, self.cin = int(kernel.shape[3]), int(kernel.shape[4])
+        else:
+            self.cin, self.cout = int(kernel.shape[3]), int(kernel.shape[4])
+        self.kernel = kernel
+        self.bias = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        self.stride = int(stride)
+        self.relu = bool(relu)
+        self._dev = {}
+
+    def desc(self, N, D, H, W, flags=0, impl=L.PCC_IMPL_AUTO, out_cstride=0, out_coffset=0):
+        f = flags | (L.PCC_CONV_BIAS if self.bias is not None else 0) | (L.PCC_CONV_RELU if self.relu else 0)
+        return L.ConvDesc(N, D, H, W, self.cin, self.cout, self.k, self.stride, int(self.transposed), f, impl,
+                          out_cstride, out_coffset)
+
+    def device_images(self, ctx, d):
+        key = ctx.device.index
+        if key not in self._dev:
+            self._dev[key] = dict(w=torch.from_numpy(self.kernel).to(ctx.device),
+                                  b=None if self.bias is None else torch.from_numpy(self.bias).to(ctx.device),
+                                  pk=None)
+        im = self._dev[key]
+        if im['pk'] is None and L.lib().pcc_conv_mfma_supported(C.byref(d)) == 1:
+            n = L.lib().pcc_conv_packed_floats(C.byref(d))
+            pk = np.empty(n, np.float32)
+            L.check(L.lib().pcc_conv_pack_weights(C.byref(d), self.kernel.ctypes.data_as(C.c_void_p),
+                                                  pk.ctypes.data_as(C.c_void_p)), 'pcc_conv_pack_weights')
+            im['pk'] = torch.from_numpy(pk).to(ctx.device)
+        return im
+
+
+def conv_out_shape(layer, x_shape):
+    N, D, H, W, _ = x_shape
+    s = layer.stride
+    if layer.transposed:
+        return (N, D * s, H * s, W * s, layer.cout)
+    o = lambda n: -(-n // s)
+    return (N, o(D), o(H), o(W), layer.cout)
+
+
+def conv3d(ctx, x, layer, residual=None, flags=0, impl=L.PCC_IMPL_AUTO, out=None, out_coffset=0):
+    """x: (N,D,H,W,Cin) float32 contiguous on ctx.device.  Returns (N,OD,OH,OW,Cout)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.device == ctx.device and x.dim() == 5
+    N, D, H, W, Cin = x.shape
+    assert Cin == layer.cin, f'expected {layer.cin} input channels, got {Cin}'
+    oshape = conv_out_shape(layer, x.shape)
+    ocs = 0
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=ctx.device)
+    else:
+        assert out.is_contiguous() and tuple(out.shape[:4]) == tuple(oshape[:4])
+        ocs = out.shape[4]
+    if residual is not None:
+        flags |= L.PCC_CONV_ADD
+        assert residual.is_contiguous() and tuple(residual.shape) == tuple(oshape)
+    d = layer.desc(N, D, H, W, flags, impl, ocs, out_coffset)
+    im = layer.device_images(ctx, d)
+    rc = L.lib().pcc_conv3d(ctx.handle, C.byref(d), _ptr(x), _ptr(im['w']), _ptr(im['pk']), _ptr(im['b']),
+                            _ptr(residual), _ptr(out), ctx.stream)
+    L.check(rc, 'pcc_conv3d')
+    return out
+
+
+def mfma_supported(layer, x_shape):
+    N, D, H, W, _ = x_shape
+    d = layer.desc(N, D, H, W)
+    return L.lib().pcc_conv_mfma_supported(C.byref(d)) == 1
+
+
+def quantize(ctx, v, medians=None, mode=L.PCC_ROUND_FLOOR_HALF, want_sym=True, want_deq=True):
+    assert v.dtype == torch.float32 and v.is_contiguous()
+    Cn = v.shape[-1]
+    sym = torch.empty(v.shape, dtype=torch.int32, device=v.device) if want_sym else None
+    deq = torch.empty_like(v) if want_deq else None
+    L.check(L.lib().pcc_quantize(ctx.handle, _ptr(v), _ptr(medians), _ptr(sym), _ptr(deq), v.numel(), Cn, mode,
+                                 ctx.stream), 'pcc_quantize')
+    return sym, deq
+
+
+def dequantize(ctx, sym, medians=None):
+    assert sym.dtype == torch.int32 and sym.is_contiguous()
+    deq = torch.empty(sym.shape, dtype=torch.float32, device=sym.device)
+    L.check(L.lib().pcc_dequantize(ctx.handle, _ptr(sym), _ptr(medians), _ptr(deq), sym.numel(), sym.shape[-1],
+                                   ctx.stream), 'pcc_dequantize')
+    return deq
+
+
+def scale_to_index(ctx, sigma, table):
+    assert sigma.dtype == torch.float32 and sigma.is_contiguous() and table.dtype == torch.float32
+    idx = torch.empty(sigma.shape, dtype=torch.int32, device=sigma.device)
+    L.check(L.lib().pcc_scale_to_index(ctx.handle, _ptr(sigma), _ptr(table), table.numel(), _ptr(idx), sigma.numel(),
+                                       ctx.stream), 'pcc_scale_to_index')
+    return idx
+
+
+def threshold_compact(ctx, x, thr, clip=False, cap=None):
+    """x: (B,D,H,W) float32; thr: (B,) float32 device tensor.  Returns (xyz (B,cap,3), counts (B,))."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, D, H, W = x.shape
+    cap = D * H * W if cap is None else int(cap)
+    xyz = torch.empty((B, cap, 3), dtype=torch.float32, device=x.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=x.device)
+    scratch = torch.empty((L.lib().pcc_threshold_scratch_ints(B, D, H, W),), dtype=torch.int32, device=x.device)
+    L.check(L.lib().pcc_threshold_compact(ctx.handle, _ptr(x), B, D, H, W, _ptr(thr), int(clip), _ptr(xyz),
+                                          _ptr(counts), cap, _ptr(scratch), ctx.stream), 'pcc_threshold_compact')
+    return xyz, counts
+
+
+def voxelize(ctx, pts, block_of, B, D, H, W):
+    """pts (n,3) int32, block_of (n,) int32 (device) -> dense (B,D,H,W) float32 of {0,1}."""
+    dense = torch.zeros((B, D, H, W), dtype=torch.float32, device=ctx.device)
+    if pts.numel():
+        assert pts.dtype == torch.int32 and pts.is_contiguous() and block_of.dtype == torch.int32
+        L.check(L.lib().pcc_voxelize(ctx.handle, _ptr(pts), _ptr(block_of), pts.shape[0], B, D, H, W, _ptr(dense),
+                                     ctx.stream), 'pcc_voxelize')
+    return dense
+
+
+def focal_loss(ctx, y_true, y_pred, gamma=2.0, alpha=0.9):
+    """src/utils/focal_loss.py:5-12 -> 0-d float32 tensor on the device."""
+    assert y_true.numel() == y_pred.numel() and y_true.is_contiguous() and y_pred.is_contiguous()
+    out = torch.empty((1,), dtype=torch.float32, device=y_pred.device)
+    scratch = torch.empty((L.lib().pcc_focal_scratch_floats(),), dtype=torch.float32, device=y_pred.device)
+    L.check(L.lib().pcc_focal_loss(ctx.handle, _ptr(y_true), _ptr(y_pred), y_true.numel(), gamma, alpha, _ptr(out),
+                                   _ptr(scratch), ctx.stream), 'pcc_focal_loss')
+    return out[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# host range coder
+# ---------------------------------------------------------------------------------------------
+class HostCdfTable:
+    """Quantised CDF table (rows, stride) + per-row size/offset, as the reference's
+    `quantized_cdf` / `cdf_length` / `offset` (src/utils/patch_gaussian_conditional.py:91-97,118)."""
+
+    def __init__(self, cdf, cdf_size, offset, precision=16, overflow_width=4):
+        self.cdf = np.ascontiguousarray(cdf, np.int32)
+        self.cdf_size = np.ascontiguousarray(cdf_size, np.int32)
+        self.offset = np.ascontiguousarray(offset, np.int32)
+        assert self.cdf.ndim == 2 and len(self.cdf_size) == len(self.offset) == self.cdf.shape[0]
+        self.struct = L.CdfTable(self.cdf.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 self.cdf_size.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 self.offset.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 self.cdf.shape[0], self.cdf.shape[1], precision, overflow_width)
+
+
+def _np_i32(a):
+    if isinstance(a, torch.Tensor):
+        a = a.numpy()
+    a = np.ascontiguousarray(a, np.int32).reshape(-1)
+    return a
+
+
+def range_encode_batch(table, data_list, index_list=None, index_mod=0, n_threads=0):
+    """data_list: per-stream int32 arrays (numpy or CPU torch).  Returns list of bytes."""
+    S = len(data_list)
+    if S == 0:
+        return []
+    data = [_np_i32(d) for d in data_list]
+    idx = None if index_list is None else [_np_i32(i) for i in index_list]
+    n = (C.c_size_t * S)(*[d.size for d in data])
+    caps = [d.size * 8 + 64 for d in data]
+    outs = [np.empty(c, np.uint8) for c in caps]
+    dp = (C.c_void_p * S)(*[d.ctypes.data for d in data])
+    ip = None if idx is None else (C.c_void_p * S)(*[i.ctypes.data for i in idx])
+    op = (C.c_void_p * S)(*[o.ctypes.data for o in outs])
+    cap = (C.c_size_t * S)(*caps)
+    olen = (C.c_size_t * S)()
+    L.check(L.lib().pcc_range_encode_batch(C.byref(table.struct), S, dp, ip, index_mod, n, op, cap, olen, n_threads),
+            'pcc_range_encode_batch')
+    return [outs[s][:olen[s]].tobytes() for s in range(S)]
+
+
+def range_decode_batch(table, strings, n_list, index_list=None, index_mod=0, n_threads=0, out=None):
+    """strings: list of bytes; n_list: symbols per stream.  Returns list of int32 numpy arrays (or
+    fills the provided `out` arrays)."""
+    S = len(strings)
+    if S == 0:
+        return []
+    bufs = [np.frombuffer(s, np.uint8) if len(s) else np.zeros(1, np.uint8) for s in strings]
+    idx = None if index_list is None else [_np_i32(i) for i in index_list]
+    outs = [np.empty(int(k), np.int32) for k in n_list] if out is None else out
+    sp = (C.c_void_p * S)(*[b.ctypes.data for b in bufs])
+    sl = (C.c_size_t * S)(*[len(s) for s in strings])
+    ip = None if idx is None else (C.c_void_p * S)(*[i.ctypes.data for i in idx])
+    n = (C.c_size_t * S)(*[int(k) for k in n_list])
+    op = (C.c_void_p * S)(*[o.ctypes.data for o in outs])
+    L.check(L.lib().pcc_range_decode_batch(C.byref(table.struct), S, sp, sl, ip, index_mod, n, op, n_threads),
+            'pcc_range_decode_batch')
+    return outs
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    pmf = np.ascontiguousarray(pmf, np.float32)
+    cdf = np.zeros(pmf.size + 1, np.int32)
+    L.check(L.lib().pcc_pmf_to_quantized_cdf(pmf.ctypes.data_as(C.c_void_p), pmf.size, precision,
+                                             cdf.ctypes.data_as(C.c_void_p)), 'pcc_pmf_to_quantized_cdf')
+    return cdf

@@ -1,0 +1,153 @@
+"""Generates tests/golden/*.npz by IMPORTING the reference's own Python modules from /root/reference
+(possible only in the build container; /root/reference does not exist on the GPU box).  The
+fixtures are DATA: inputs + the outputs the reference code produced for them.
+
+Run:  python tests/golden/make_golden.py
+
+Importable as-is (numpy only):
+    src/model_syntax.py, src/utils/octree_coding.py
+Importable with shims (documented, no reference code is altered):
+    src/model_opt.py + src/utils/pc_metric.py need `pyntcloud` and `numba` at import time.  Neither is
+    used by the functions exercised here except `numba.njit` as a decorator (identity shim) and
+    `cKDTree.query(n_jobs=-1)` which scipy>=1.6 renamed to `workers` (kwarg-translating shim).
+NOT importable (TensorFlow 1.15 / tensorflow-compression 1.3 absent): model_transforms.py,
+model_types.py, focal_loss.py, patch_gaussian_conditional.py -> no vectors; the oracle for those is
+marked "parity unpinned".
+"""
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference/src'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _shims():
+    numba = types.ModuleType('numba')
+    numba.njit = lambda f=None, **kw: (f if f is not None else (lambda g: g))
+    sys.modules['numba'] = numba
+    pyntcloud = types.ModuleType('pyntcloud')
+    pyntcloud.PyntCloud = object
+    sys.modules['pyntcloud'] = pyntcloud
+    import scipy.spatial
+    ck = types.ModuleType('scipy.spatial.ckdtree')  # removed module path used by model_opt.py:3
+    _base = scipy.spatial.cKDTree
+
+    class cKDTree(_base):
+        def query(self, x, k=1, eps=0, p=2, distance_upper_bound=np.inf, n_jobs=None, workers=1):
+            if n_jobs is not None:
+                workers = n_jobs
+            return super().query(x, k=k, eps=eps, p=p, distance_upper_bound=distance_upper_bound, workers=workers)
+
+    ck.cKDTree = cKDTree
+    sys.modules['scipy.spatial.ckdtree'] = ck
+    scipy.spatial.cKDTree = cKDTree
+
+
+def main():
+    sys.path.insert(0, REF)
+    _shims()
+    import model_syntax
+    from utils import octree_coding
+    import model_opt
+    from utils import pc_metric
+
+    rng = np.random.default_rng(20260928)
+
+    # ---- container (model_syntax.py:20-58)
+    cases = []
+    cases.append(dict(binstr=[3, 129], blocks=[([b'abc', b'efg'], 35), ([b'xyz', b'uvw'], 7)], resolution=1024, level=4))
+    cases.append(dict(binstr=[1, 2, 3], blocks=[([b'abc', b'efg'], 35), ([b'xyz', b'uvw'], 7)], resolution=512, level=4))
+    cases.append(dict(binstr=[255], blocks=[([b''], 0)], resolution=64, level=1))
+    big = [([bytes(rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8)) for _ in range(2)],
+            int(rng.integers(0, 256))) for _ in range(17)]
+    cases.append(dict(binstr=list(map(int, rng.integers(1, 256, 9))), blocks=big, resolution=1024, level=3))
+    syn = {}
+    for i, c in enumerate(cases):
+        data = model_syntax.save_compressed_file(c['binstr'], c['blocks'], c['resolution'], c['level'])
+        r, l, b, blocks = model_syntax.load_compressed_file(io.BytesIO(data))
+        assert r == c['resolution'] and l == c['level']
+        syn[f'c{i}_bytes'] = np.frombuffer(data, np.uint8)
+        syn[f'c{i}_binstr'] = np.array(c['binstr'], np.int64)
+        syn[f'c{i}_res_level'] = np.array([c['resolution'], c['level']], np.int64)
+        syn[f'c{i}_thr'] = np.array([t for _, t in c['blocks']], np.int64)
+        syn[f'c{i}_nstr'] = np.array([len(c['blocks'][0][0])], np.int64)
+        flat = [s for ss, _ in c['blocks'] for s in ss]
+        syn[f'c{i}_strlens'] = np.array([len(s) for s in flat], np.int64)
+        syn[f'c{i}_strcat'] = np.frombuffer(b''.join(flat), np.uint8)
+    syn['n_cases'] = np.array([len(cases)])
+    np.savez_compressed(os.path.join(OUT, 'model_syntax.npz'), **syn)
+
+    # ---- octree (utils/octree_coding.py:68-169)
+    oc = {}
+    # level=1 is excluded: the reference's departition_octree raises IndexError (pop from an empty
+    # parents_stack, octree_coding.py:164) whenever level == 1 -- a reference quirk, not a vector.
+    specs = [(64, 2, 300, 3), (128, 3, 2000, 3), (256, 4, 3000, 6), (64, 3, 50, 3), (32, 5, 400, 3)]
+    for i, (res, level, npts, ncol) in enumerate(specs):
+        # clustered cloud so that not all blocks are occupied
+        centers = rng.integers(0, res, (4, 3))
+        pts = np.clip(centers[rng.integers(0, 4, npts)] + rng.normal(0, res / 10, (npts, 3)), 0, res - 1)
+        pts = np.unique(np.floor(pts), axis=0)
+        if ncol == 6:
+            pts = np.hstack([pts, rng.normal(size=(len(pts), 3)).round(3)])
+        blocks, binstr = octree_coding.partition_octree(pts, [0, 0, 0], [res] * 3, level)
+        blocks_rec, binstr_rec = octree_coding.partition_octree_rec(pts, [0, 0, 0], [res] * 3, level)
+        assert list(binstr) == list(binstr_rec)
+        dep = octree_coding.departition_octree(blocks, binstr, [0, 0, 0], [res] * 3, level)
+        oc[f'o{i}_spec'] = np.array([res, level], np.int64)
+        oc[f'o{i}_points'] = pts
+        oc[f'o{i}_binstr'] = np.array(binstr, np.int64)
+        oc[f'o{i}_block_len'] = np.array([len(b) for b in blocks], np.int64)
+        oc[f'o{i}_blocks_cat'] = np.vstack(blocks)
+        oc[f'o{i}_depart_cat'] = np.vstack(dep)
+    oc['n_cases'] = np.array([len(specs)])
+    np.savez_compressed(os.path.join(OUT, 'octree_coding.npz'), **oc)
+
+    # ---- thresholds + metrics (model_opt.py:9-77, utils/pc_metric.py:76-138)
+    mo = {}
+    n_cases = 4
+    for i in range(n_cases):
+        R = 16
+        block = np.unique(rng.integers(0, R, (int(rng.integers(20, 200)), 3)), axis=0).astype(np.float64)
+        dense = np.zeros((R, R, R), np.float32)
+        dense[tuple(block.astype(int).T)] = 1
+        # a smooth "network output": blurred occupancy + noise, clipped as model_types.py:202 does
+        from scipy.ndimage import gaussian_filter
+        x_hat = np.clip(gaussian_filter(dense, 0.7) * 2.5 + rng.normal(0, 0.02, dense.shape), 0, 1).astype(np.float32)
+        thresholds = np.linspace(0, 1.0, 2 ** 8)
+        for fixed in (False, True):
+            names, best = model_opt.compute_optimal_thresholds(block, x_hat, thresholds, 64, normals=None,
+                                                               opt_metrics=['d1_mse', 'd1_sum_mean'],
+                                                               max_deltas=[np.inf], fixed_threshold=fixed)
+            mo[f'm{i}_best_fixed{int(fixed)}'] = np.array(best, np.int64)
+            mo[f'm{i}_names_fixed{int(fixed)}'] = np.array(names)
+        pa = np.argwhere(x_hat > thresholds[100]).astype('float32')
+        met = pc_metric.compute_metrics(block, pa, 63)
+        mo[f'm{i}_block'] = block
+        mo[f'm{i}_x_hat'] = x_hat
+        mo[f'm{i}_pa100'] = pa
+        mo[f'm{i}_metric_keys'] = np.array(sorted(met.keys()))
+        mo[f'm{i}_metric_vals'] = np.array([met[k] for k in sorted(met.keys())], np.float64)
+        pal = model_opt.build_points_threshold(x_hat, thresholds, len(block), max_delta=2.0)
+        mo[f'm{i}_bpt_idx'] = np.array([j for j, _ in pal], np.int64)
+        mo[f'm{i}_bpt_len'] = np.array([len(p) for _, p in pal], np.int64)
+    # d2 (normals) case
+    R = 16
+    block = np.unique(rng.integers(0, R, (150, 3)), axis=0).astype(np.float64)
+    nrm = rng.normal(size=block.shape)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    p2 = np.unique(np.clip(block + rng.integers(-1, 2, block.shape), 0, R - 1), axis=0).astype(np.float32)
+    met = pc_metric.compute_metrics(block, p2, 63, p1_n=nrm)
+    mo['d2_block'], mo['d2_normals'], mo['d2_p2'] = block, nrm, p2
+    mo['d2_metric_keys'] = np.array(sorted(met.keys()))
+    mo['d2_metric_vals'] = np.array([met[k] for k in sorted(met.keys())], np.float64)
+    mo['n_cases'] = np.array([n_cases])
+    np.savez_compressed(os.path.join(OUT, 'model_opt.npz'), **mo)
+    print('golden fixtures written to', OUT)
+
+
+if __name__ == '__main__':
+    main()

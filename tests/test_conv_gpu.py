@@ -1,0 +1,118 @@
+"""GPU parity: HIP conv kernels (generic + MFMA) through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from pcc_geo_cnn_v2_amd import _lib as L
+from pcc_geo_cnn_v2_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+# stated fp32 tolerance for one conv layer: |gpu - oracle(double acc)| <= TOL * (1 + max|ref|)
+TOL = 2e-5
+
+
+def _run(ctx, O, N, D, H, W, cin, cout, k, s, tr, bias, relu, res, impl, seed=0, clip=False):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, D, H, W, cin)).astype(np.float32)
+    x[rng.random(x.shape) < 0.3] = 0
+    wshape = (k, k, k, cout, cin) if tr else (k, k, k, cin, cout)
+    w = (rng.standard_normal(wshape) / np.sqrt(k ** 3 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) if bias else None
+    layer = ops.ConvLayer(w, b, s, tr, relu)
+    ref = (O.conv3d_transpose if tr else O.conv3d)(x, w, b, s, relu)
+    r = None
+    if res:
+        r = rng.standard_normal(ref.shape).astype(np.float32)
+        ref = ref + r
+    if clip:
+        ref = np.clip(ref, 0, 1)
+    xt = torch.from_numpy(x).to(ctx.device)
+    rt = None if r is None else torch.from_numpy(r).to(ctx.device)
+    if impl == L.PCC_IMPL_MFMA and not ops.mfma_supported(layer, x.shape):
+        pytest.fail(f'MFMA path does not cover cin={cin} cout={cout} k={k} s={s} tr={tr} dims={(D, H, W)}')
+    out = ops.conv3d(ctx, xt, layer, residual=rt, impl=impl, flags=L.PCC_CONV_CLIP01 if clip else 0)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    bound = TOL * (1 + np.abs(ref).max())
+    assert err <= bound, f'max err {err} > {bound}; first bad {np.argwhere(np.abs(got - ref) > bound)[:5]}'
+    return got
+
+
+GENERIC_CASES = [
+    # N, D, H, W, cin, cout, k, s, tr
+    (2, 8, 8, 8, 1, 1, 9, 2, False), (1, 8, 8, 8, 1, 2, 5, 2, False), (1, 7, 9, 6, 3, 5, 3, 1, False),
+    (1, 7, 9, 6, 3, 5, 3, 2, False), (2, 1, 1, 1, 2, 2, 5, 2, True), (1, 4, 5, 3, 2, 1, 9, 2, True),
+    (1, 5, 4, 6, 4, 3, 3, 1, True), (1, 5, 4, 6, 4, 3, 3, 2, True), (1, 8, 8, 8, 16, 16, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize('case', GENERIC_CASES)
+def test_generic_conv_matches_oracle(ctx, oracle, case):
+    N, D, H, W, cin, cout, k, s, tr = case
+    _run(ctx, oracle, N, D, H, W, cin, cout, k, s, tr, True, True, True, L.PCC_IMPL_GENERIC)
+    _run(ctx, oracle, N, D, H, W, cin, cout, k, s, tr, False, False, False, L.PCC_IMPL_GENERIC, seed=1)
+
+
+# every (cin, cout, k, stride, transposed) the c1/c2/c3/c3p graphs use, at the three row widths
+MFMA_CASES = []
+for dims in [(8, 16, 16), (6, 8, 8), (4, 4, 4), (4, 8, 32)]:
+    for (cin, cout) in [(16, 16), (32, 32), (64, 64)]:
+        MFMA_CASES.append((1,) + dims + (cin, cout, 3, 1, False))
+        MFMA_CASES.append((1,) + dims + (cin, cout, 3, 1, True))
+for dims in [(8, 16, 32), (4, 8, 16), (8, 8, 8)]:
+    for (cin, cout) in [(16, 32), (32, 64), (64, 64), (32, 32)]:
+        MFMA_CASES.append((1,) + dims + (cin, cout, 3, 2, False))
+    MFMA_CASES.append((1,) + dims + (32, 32, 5, 2, False))
+for dims in [(4, 8, 16), (3, 8, 8), (4, 4, 4), (2, 4, 32)]:
+    for (cin, cout) in [(64, 64), (64, 32), (32, 16), (32, 32)]:
+        MFMA_CASES.append((1,) + dims + (cin, cout, 3, 2, True))
+    MFMA_CASES.append((1,) + dims + (32, 32, 5, 2, True))
+for dims in [(8, 16, 32), (16, 16, 64)]:
+    MFMA_CASES += [(2,) + dims + (1, 16, 3, 2, False), (1,) + dims + (1, 32, 9, 2, False),
+                   (1,) + dims + (1, 16, 9, 2, False), (1,) + dims + (1, 32, 3, 2, False)]
+for dims in [(4, 8, 8), (6, 10, 16)]:
+    MFMA_CASES += [(2,) + dims + (16, 1, 3, 1, True), (1,) + dims + (32, 1, 3, 1, True), (1,) + dims + (32, 1, 9, 2, True)]
+
+
+@pytest.mark.parametrize('case', MFMA_CASES)
+def test_mfma_conv_matches_oracle(ctx, oracle, case):
+    N, D, H, W, cin, cout, k, s, tr = case
+    _run(ctx, oracle, N, D, H, W, cin, cout, k, s, tr, True, True, cout > 1, L.PCC_IMPL_MFMA, seed=3)
+
+
+def test_mfma_batch_partial_tiles_and_plain(ctx, oracle):
+    # dims that are not multiples of the tile (partial tiles), batch > 1, no bias/relu/residual
+    _run(ctx, oracle, 3, 5, 10, 16, 16, 16, 3, 1, False, False, False, False, L.PCC_IMPL_MFMA, seed=5)
+    _run(ctx, oracle, 2, 3, 5, 16, 32, 16, 3, 2, True, False, False, False, L.PCC_IMPL_MFMA, seed=6)
+    _run(ctx, oracle, 2, 6, 10, 32, 16, 32, 3, 2, False, True, False, False, L.PCC_IMPL_MFMA, seed=7)
+    _run(ctx, oracle, 1, 6, 10, 16, 16, 1, 3, 1, True, True, True, False, L.PCC_IMPL_MFMA, seed=8, clip=True)
+
+
+def test_mfma_is_bit_deterministic_and_batch_invariant(ctx):
+    """sigma_hat must not depend on batch position / launch geometry."""
+    rng = np.random.default_rng(11)
+    w = (rng.standard_normal((3, 3, 3, 64, 64)) / 40).astype(np.float32)
+    layer = ops.ConvLayer(w, rng.standard_normal(64).astype(np.float32), 1, True, True)
+    x = torch.from_numpy(rng.standard_normal((5, 8, 8, 8, 64)).astype(np.float32)).to(ctx.device)
+    a = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
+    b = ops.conv3d(ctx, x[3:4].contiguous(), layer, impl=L.PCC_IMPL_MFMA)
+    c = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
+    torch.cuda.synchronize()
+    assert torch.equal(a, c)
+    assert torch.equal(a[3:4], b)
+
+
+def test_concat_mode_channel_offset(ctx, oracle):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((1, 4, 4, 4, 2)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 3, 2, 3)).astype(np.float32)
+    layer = ops.ConvLayer(w, None, 1, False, False)
+    out = torch.zeros((1, 4, 4, 4, 8), device=ctx.device)
+    ops.conv3d(ctx, torch.from_numpy(x).to(ctx.device), layer, out=out, out_coffset=4)
+    ref = oracle.conv3d(x, w)
+    got = out.cpu().numpy()
+    assert np.abs(got[..., 4:7] - ref).max() < 1e-4
+    assert np.all(got[..., :4] == 0) and np.all(got[..., 7] == 0)
