@@ -534,11 +534,11 @@ inline int base_w(const pcc_conv_desc* d) {  // x extent of the grid the rows li
 
 Plan make_plan(const pcc_conv_desc* d) {
     Plan p;
-    if (d->out_cstride != 0 && (d->out_cstride % 4 != 0 || d->out_coffset % 4 != 0)) return p;
+    const bool out_vec_ok = d->out_cstride == 0 || (d->out_cstride % 4 == 0 && d->out_coffset % 4 == 0);
     const int k = d->k, s = d->stride;
     const bool even = (d->D % 2 == 0) && (d->H % 2 == 0) && (d->W % 2 == 0);
     if (!d->transposed && d->Cin == 1) {
-        if (s == 2 && even && (k == 3 || k == 9) && (d->Cout == 16 || d->Cout == 32) && base_w(d) % 16 == 0) p.kind = K_CIN1;
+        if (out_vec_ok && s == 2 && even && (k == 3 || k == 9) && (d->Cout == 16 || d->Cout == 32) && base_w(d) % 16 == 0) p.kind = K_CIN1;
         return p;
     }
     if (d->transposed && d->Cout == 1) {
@@ -546,6 +546,7 @@ Plan make_plan(const pcc_conv_desc* d) {
         else if (s == 2 && k == 9 && d->Cin == 32 && d->W % 8 == 0) p.kind = K_COUT1;
         return p;
     }
+    if (!out_vec_ok) return p;
     if (d->Cin % 16 || d->Cout % 16 || d->Cin > 64 || d->Cout > 64 || d->Cin == 48 || d->Cout == 48) return p;
     const int bw = base_w(d);
     const int tx = bw % 16 == 0 ? 16 : (bw == 8 ? 8 : (bw == 4 ? 4 : 0));

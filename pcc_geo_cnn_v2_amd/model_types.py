@@ -1,0 +1,501 @@
+"""Compression models -- the interface of /root/reference/src/model_types.py:179-416
+(CompressionModel / CompressionModelV1 / CompressionModelV2: compress(), decompress(),
+compress_blocks(), decompress_blocks()) on top of the HIP kernels.
+
+MI355X-first differences (results identical):
+  * blocks are processed `batch_size` at a time, resident in HBM, instead of one sess.run per block
+    (reference: model_types.py:192-198,224-230);
+  * sparse_to_dense, thresholding and np.argwhere run on the GPU (voxelize / threshold_compact);
+  * the range coder runs on host threads, one stream per block, overlapped with the synthesis
+    transform of the same (encoder) or previous (decoder) chunk;
+  * the encoder obtains z_hat / y_hat from the quantiser directly instead of range-decoding the
+    string it just produced (model_types.py:383,387): the values are identical by construction.
+`sess` in the reference's signatures is an `ops.Context` here (None = the default GPU context).
+"""
+import logging
+import os
+import pprint
+from enum import Enum
+
+import numpy as np
+import torch
+from scipy.spatial import cKDTree
+
+from . import _lib as L
+from . import model_transforms as MT
+from . import ops
+from .entropy_models import EntropyBottleneck, GaussianConditional, scale_table
+from .model_opt import compute_optimal_thresholds
+from .model_transforms import TransformType
+from .utils.octree_coding import departition_octree
+from .utils.pc_metric import compute_metrics
+
+logger = logging.getLogger(__name__)
+
+CHECKPOINT_FILE = 'model.npz'
+
+
+def sparse_to_dense(block, x_shape, data_format):
+    """Host version kept for API parity (model_types.py:108-114); the codec uses ops.voxelize."""
+    x_val = np.zeros(x_shape, dtype=np.float32)
+    block = np.asarray(block).astype(np.uint32)
+    if data_format == 'channels_first':
+        x_val[0, 0, block[:, 0], block[:, 1], block[:, 2]] = 1.0
+    else:
+        x_val[0, block[:, 0], block[:, 1], block[:, 2], 0] = 1.0
+    return x_val
+
+
+def get_normals_if(x, with_normals):
+    return x[:, x.shape[1] - 3:x.shape[1]] if with_normals else None
+
+
+def select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics, points, resolution, with_normals,
+                               opt_groups=('d1', 'd2')):
+    """Selects best opt_metric for each opt_group (model_types.py:128-176)."""
+    assert len(opt_metrics) == len(x_hat_list), f'lengths of opt_metrics {len(opt_metrics)} and x_hat_list' + \
+                                                f' {len(x_hat_list)} should be equal'
+    om_groups = [[(x, y, i) for i, (x, y) in enumerate(zip(opt_metrics, x_hat_list))
+                  if x.startswith(group)] for group in opt_groups]
+    bbox_min = [0, 0, 0]
+    bbox_max = [resolution] * 3
+    t1 = cKDTree(points[:, :3])
+    metadata = []
+    for group, om_group in zip(opt_groups, om_groups):
+        metric_key = f'{group}_psnr'
+        if len(om_group) == 0:
+            continue
+        om_names, cur_x_hat_list, indexes = zip(*om_group)
+        cur_blocks_depart = [departition_octree(x, binstr, bbox_min, bbox_max, level) for x in cur_x_hat_list]
+        cur_blocks_full = [np.vstack(x) for x in cur_blocks_depart]
+        cur_metrics_full = [compute_metrics(points[:, :3], x, resolution - 1, p1_n=get_normals_if(points, with_normals),
+                                            t1=t1) if len(x) else {metric_key: -np.inf} for x in cur_blocks_full]
+        cur_metrics = [x[metric_key] for x in cur_metrics_full]
+        local_best_idx = int(np.argmax(cur_metrics))
+        best_idx = indexes[local_best_idx]
+        metadata.append({'idx': best_idx,
+                         'metrics': cur_metrics_full[local_best_idx],
+                         'x_hat_list': cur_x_hat_list[local_best_idx],
+                         'blocks_depart': cur_blocks_depart[local_best_idx],
+                         'blocks_full': cur_blocks_full[local_best_idx]})
+        logger.info(f'Group {group} : {metric_key} best idx {best_idx} {opt_metrics[best_idx]}\n' +
+                    pprint.pformat(dict(zip(om_names, [f"{x:.2f}" for x in cur_metrics]))))
+    return metadata
+
+
+class _Pinned:
+    """Cache of pinned host staging buffers keyed by (tag, shape, dtype)."""
+
+    def __init__(self):
+        self._b = {}
+
+    def get(self, tag, shape, dtype):
+        key = (tag, tuple(shape), dtype)
+        if key not in self._b:
+            self._b[key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+        return self._b[key]
+
+
+class CompressionModel:
+    def __init__(self, n_thresholds=2 ** 8, data_format='channels_first', batch_size=32,
+                 round_mode=L.PCC_ROUND_FLOOR_HALF, coder_threads=0, seed=42):
+        self.thresholds = np.linspace(0, 1.0, n_thresholds)
+        self.data_format = data_format
+        self.batch_size = int(batch_size)
+        self.round_mode = round_mode
+        self.coder_threads = coder_threads
+        self.seed = seed
+        self.x_shape = None
+        self._pinned = _Pinned()
+        self._dev_cache = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _ctx(self, sess):
+        return sess if isinstance(sess, ops.Context) else ops.get_context(None)
+
+    def _dev(self, ctx, name, arr):
+        key = (ctx.device.index, name)
+        if key not in self._dev_cache:
+            self._dev_cache[key] = torch.from_numpy(np.ascontiguousarray(arr)).to(ctx.device)
+        return self._dev_cache[key]
+
+    def _spatial(self, x_shape):
+        x_shape = [int(v) for v in x_shape]
+        if len(x_shape) == 3:
+            return tuple(x_shape)
+        assert len(x_shape) == 5
+        return tuple(x_shape[2:5]) if self.data_format == 'channels_first' else tuple(x_shape[1:4])
+
+    def _thr32(self, idx):
+        # the reference compares float32 x_hat with a float64 scalar under numpy 1.18 value-based
+        # casting, i.e. in float32
+        return np.float32(self.thresholds[idx])
+
+    def _voxelize(self, ctx, blocks, dhw):
+        D, H, W = dhw
+        B = len(blocks)
+        pts = np.concatenate([np.asarray(b)[:, :3] for b in blocks]).astype(np.uint32).astype(np.int32)
+        bof = np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(blocks)])
+        return ops.voxelize(ctx, torch.from_numpy(pts).to(ctx.device), torch.from_numpy(bof).to(ctx.device), B, D, H, W)
+
+    def _extract_points(self, ctx, x_hat, thr_idx, clip):
+        """x_hat (B,D,H,W) device; thr_idx list of ints -> list of (n,3) float32 numpy arrays."""
+        B = x_hat.shape[0]
+        thr = torch.from_numpy(np.array([self._thr32(t) for t in thr_idx], np.float32)).to(ctx.device)
+        xyz, counts = ops.threshold_compact(ctx, x_hat, thr, clip=clip)
+        return xyz, counts
+
+    @staticmethod
+    def _gather_points(xyz, counts):
+        cnt = counts.cpu().numpy()
+        parts = [xyz[b, :int(cnt[b])] for b in range(len(cnt))]
+        flat = torch.cat(parts).cpu().numpy() if len(parts) else np.zeros((0, 3), np.float32)
+        out, p = [], 0
+        for n in cnt:
+            out.append(flat[p:p + int(n)].copy())
+            p += int(n)
+        return out
+
+    # ------------------------------------------------------------------ weights / checkpoints
+    def _transforms(self):
+        raise NotImplementedError
+
+    def init_weights(self, seed=None):
+        """Seeded Glorot-uniform kernels / zero biases (Keras defaults) and tfc default entropy models:
+        what tf.global_variables_initializer() gives before saver.restore (compress_octree.py:83-92)."""
+        rng = np.random.default_rng(self.seed if seed is None else seed)
+        for prefix, tr, cin in self._transforms():
+            MT.init_transform(tr, cin, rng)
+        self._init_entropy(None)
+
+    def get_weights(self):
+        out = {}
+        for prefix, tr, _ in self._transforms():
+            out.update(MT.get_weights(tr, prefix))
+        out.update(self._entropy_weights())
+        return out
+
+    def set_weights(self, params):
+        for prefix, tr, _ in self._transforms():
+            MT.set_weights(tr, prefix, params)
+        self._init_entropy(params)
+        self._dev_cache.clear()
+
+    def save_checkpoint(self, checkpoint_dir):
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        np.savez(os.path.join(checkpoint_dir, CHECKPOINT_FILE), **self.get_weights())
+
+    def restore(self, checkpoint_dir):
+        path = os.path.join(checkpoint_dir, CHECKPOINT_FILE)
+        assert os.path.exists(path), f'Checkpoint {checkpoint_dir} was not found'
+        with np.load(path) as f:
+            self.set_weights({k: f[k] for k in f.files})
+
+    # ------------------------------------------------------------------ block loops
+    def compress_blocks(self, sess, blocks, binstr, points, resolution, level, with_normals=False,
+                        opt_metrics=('d1_mse',), max_deltas=(np.inf,), fixed_threshold=False, debug=False):
+        """Uses the compression model to compress a point cloud (model_types.py:184-218)."""
+        ctx = self._ctx(sess)
+        dhw = self._spatial(self.x_shape)
+        strings_list, threshold_list, debug_t_list, x_hat_list = [], [], [], []
+        opt_metrics_ret = None
+        half = len(self.thresholds) // 2
+        for c0 in range(0, len(blocks), self.batch_size):
+            chunk = blocks[c0:c0 + self.batch_size]
+            x = self._voxelize(ctx, chunk, dhw)
+            enc = self._encode_batch(ctx, x, debug)
+            x_hat = enc['x_hat']
+            if fixed_threshold:
+                # compute_optimal_thresholds' fixed branch (model_opt.py:27-31): index len//2 for every metric
+                n_m = len(max_deltas) * len(opt_metrics)
+                opt_metrics_ret = [f'{m}_{d}' for d in max_deltas for m in opt_metrics]
+                xyz, counts = self._extract_points(ctx, x_hat, [half] * len(chunk), clip=True)
+                strings = enc['finish']()
+                pts = self._gather_points(xyz, counts)
+                for j in range(len(chunk)):
+                    threshold_list.append([half] * n_m)
+                    x_hat_list.append([pts[j]] * n_m)
+            else:
+                strings = enc['finish']()
+                xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)
+                for j, block in enumerate(chunk):
+                    normals = get_normals_if(block, with_normals)
+                    opt_metrics_ret, best = compute_optimal_thresholds(block, xh[j], self.thresholds, resolution,
+                                                                       normals=normals, opt_metrics=opt_metrics,
+                                                                       max_deltas=max_deltas, fixed_threshold=False)
+                    threshold_list.append(best)
+                    x_hat_list.append([np.argwhere(xh[j] > self._thr32(t)).astype(np.float32) for t in best])
+            strings_list.extend(strings)
+            debug_t_list.extend(enc['debug'])
+        # block -> opt metric to opt metric -> block
+        threshold_list = list(zip(*threshold_list))
+        x_hat_list = list(zip(*x_hat_list))
+        metadata = select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics_ret, points, resolution, with_normals)
+        data_list = [list(zip(strings_list, threshold_list[x['idx']])) for x in metadata]
+        return data_list, metadata, debug_t_list
+
+    def decompress_blocks(self, sess, blocks, x_shape, debug=False):
+        """Uses the decompression model to decompress a point cloud (model_types.py:220-238).
+        Software pipeline over chunks: the host range decoder of chunk k overlaps the synthesis of k-1."""
+        ctx = self._ctx(sess)
+        dhw = self._spatial(x_shape)
+        chunks = [blocks[c0:c0 + self.batch_size] for c0 in range(0, len(blocks), self.batch_size)]
+        state = [None] * len(chunks)
+        results = [None] * len(chunks)
+        for k in range(len(chunks) + 1):
+            if k < len(chunks):
+                state[k] = self._decode_phase_a(ctx, [s for s, _ in chunks[k]], dhw)
+            if k >= 1:
+                dec = self._decode_phase_b(ctx, state[k - 1], dhw, debug)
+                thr_idx = [int(t) for _, t in chunks[k - 1]]
+                xyz, counts = self._extract_points(ctx, dec['x_hat'], thr_idx, clip=False)  # decoder does not clip (:232-233)
+                results[k - 1] = (xyz, counts, dec['debug'])
+                state[k - 1] = None
+        dec_blocks, debug_t_list = [], []
+        for xyz, counts, dbg in results:
+            dec_blocks.extend(self._gather_points(xyz, counts))
+            debug_t_list.extend(dbg)
+        return dec_blocks, debug_t_list
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class CompressionModelV1(CompressionModel):
+    def __init__(self, num_filters=32,
+                 analysis_transform_type=TransformType.AnalysisTransformV1,
+                 synthesis_transform_type=TransformType.SynthesisTransformV1, *args, **kwargs):
+        self.num_filters = num_filters
+        self.analysis_transform_class = analysis_transform_type.value
+        self.synthesis_transform_class = synthesis_transform_type.value
+        self.analysis_transform = self.synthesis_transform = None
+        self.entropy_bottleneck = None
+        super().__init__(*args, **kwargs)
+
+    def train(self, x, gamma, alpha, lmbda):
+        raise NotImplementedError('training is out of scope of the MI355X hot path (SURVEY.md §2); '
+                                  'the focal-loss reduction is available as utils.focal_loss.focal_loss')
+
+    def _transforms(self):
+        t = []
+        if self.analysis_transform is not None:
+            t.append(('analysis', self.analysis_transform, 1))
+        t.append(('synthesis', self.synthesis_transform, self.num_filters))
+        return t
+
+    def _init_entropy(self, params):
+        eb_params = tables = None
+        if params is not None and 'entropy_bottleneck/quantiles' in params:
+            eb_params = {k.split('/', 1)[1]: params[k] for k in params if k.startswith('entropy_bottleneck/')}
+            if 'quantized_cdf' in eb_params:
+                tables = (eb_params.pop('quantized_cdf'), eb_params.pop('cdf_length'), eb_params.pop('offset'))
+        self.entropy_bottleneck = EntropyBottleneck(self.num_filters, params=eb_params, tables=tables, seed=self.seed)
+
+    def _entropy_weights(self):
+        eb = self.entropy_bottleneck
+        out = {f'entropy_bottleneck/{k}': v for k, v in eb.params.items()}
+        out.update({'entropy_bottleneck/quantized_cdf': eb.quantized_cdf, 'entropy_bottleneck/cdf_length': eb.cdf_length,
+                    'entropy_bottleneck/offset': eb.offset})
+        return out
+
+    def compress(self, x_shape):
+        """Initializes the compression model (model_types.py:283-295)."""
+        self.x_shape = [int(v) for v in x_shape]
+        self.analysis_transform = self.analysis_transform_class(self.num_filters, data_format=self.data_format)
+        self.synthesis_transform = self.synthesis_transform_class(self.num_filters, data_format=self.data_format)
+        self.init_weights()
+
+    def decompress(self):
+        """Initializes the decompression model (model_types.py:297-309)."""
+        self.analysis_transform = None
+        self.synthesis_transform = self.synthesis_transform_class(self.num_filters, data_format=self.data_format)
+        self.init_weights()
+
+    # ---- batched graph
+    def _encode_batch(self, ctx, x, debug):
+        B = x.shape[0]
+        eb = self.entropy_bottleneck
+        med = self._dev(ctx, 'medians', eb.medians)
+        y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
+        ysym, y_hat = ops.quantize(ctx, y, med, self.round_mode)
+        ysym_h = self._pinned.get('ysym', ysym.shape, torch.int32)
+        ysym_h.copy_(ysym, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ctx.device))
+        x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+
+        def finish():
+            ev.synchronize()
+            ys = ops.range_encode_batch(eb.table, [ysym_h[b] for b in range(B)], None, self.num_filters, self.coder_threads)
+            return [(s,) for s in ys]
+
+        dbg = [{'y_hat': _np(y_hat[b:b + 1]), 'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))} for b in range(B)] if debug else [None] * B
+        return dict(x_hat=x_hat, finish=finish, debug=dbg)
+
+    def _decode_phase_a(self, ctx, strings, dhw):
+        B = len(strings)
+        eb = self.entropy_bottleneck
+        yshape = (B, dhw[0] // 8, dhw[1] // 8, dhw[2] // 8, self.num_filters)
+        ysym_h = torch.empty(yshape, dtype=torch.int32, pin_memory=True)
+        n = int(np.prod(yshape[1:]))
+        ops.range_decode_batch(eb.table, [s[0] for s in strings], [n] * B, None, self.num_filters, self.coder_threads,
+                               out=[ysym_h[b].numpy() for b in range(B)])
+        return dict(ysym_h=ysym_h)
+
+    def _decode_phase_b(self, ctx, st, dhw, debug):
+        eb = self.entropy_bottleneck
+        med = self._dev(ctx, 'medians', eb.medians)
+        ysym = st['ysym_h'].to(ctx.device, non_blocking=True)
+        y_hat = ops.dequantize(ctx, ysym, med)
+        x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+        B = x_hat.shape[0]
+        dbg = [{'y_hat': _np(y_hat[b:b + 1]), 'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))} for b in range(B)] if debug else [None] * B
+        return dict(x_hat=x_hat.contiguous(), debug=dbg)
+
+
+class CompressionModelV2(CompressionModel):
+    def __init__(self, num_filters=32,
+                 analysis_transform_type=TransformType.AnalysisTransformV1,
+                 synthesis_transform_type=TransformType.SynthesisTransformV1,
+                 hyper_analysis_transform_type=TransformType.HyperAnalysisTransform,
+                 hyper_synthesis_transform_type=TransformType.HyperSynthesisTransform,
+                 scales_min=0.11, scales_max=256, scales_levels=64, *args, **kwargs):
+        self.num_filters = num_filters
+        self.analysis_transform_class = analysis_transform_type.value
+        self.synthesis_transform_class = synthesis_transform_type.value
+        self.hyper_analysis_transform_class = hyper_analysis_transform_type.value
+        self.hyper_synthesis_transform_class = hyper_synthesis_transform_type.value
+        self.scale_table = scale_table(scales_min, scales_max, scales_levels)
+        self.analysis_transform = self.synthesis_transform = None
+        self.hyper_analysis_transform = self.hyper_synthesis_transform = None
+        self.entropy_bottleneck = self.conditional_bottleneck = None
+        super().__init__(*args, **kwargs)
+
+    def train(self, x, gamma, alpha, lmbda):
+        raise NotImplementedError('training is out of scope of the MI355X hot path (SURVEY.md §2); '
+                                  'the focal-loss reduction is available as utils.focal_loss.focal_loss')
+
+    def _transforms(self):
+        t = []
+        if self.analysis_transform is not None:
+            t.append(('analysis', self.analysis_transform, 1))
+            t.append(('hyper_analysis', self.hyper_analysis_transform, self.num_filters))
+        t.append(('hyper_synthesis', self.hyper_synthesis_transform, self.num_filters))
+        t.append(('synthesis', self.synthesis_transform, self.num_filters))
+        return t
+
+    def _init_entropy(self, params):
+        CompressionModelV1._init_entropy(self, params)
+        tables = None
+        if params is not None and 'gaussian_conditional/quantized_cdf' in params:
+            tables = tuple(params[f'gaussian_conditional/{k}'] for k in ('quantized_cdf', 'cdf_length', 'offset'))
+        if self.conditional_bottleneck is None or tables is not None:
+            self.conditional_bottleneck = GaussianConditional(self.scale_table, tables=tables)
+
+    def _entropy_weights(self):
+        out = CompressionModelV1._entropy_weights(self)
+        gc = self.conditional_bottleneck
+        out.update({'gaussian_conditional/quantized_cdf': gc.quantized_cdf, 'gaussian_conditional/cdf_length': gc.cdf_length,
+                    'gaussian_conditional/offset': gc.offset})
+        return out
+
+    def compress(self, x_shape):
+        """Initializes the compression model (model_types.py:371-391)."""
+        self.x_shape = [int(v) for v in x_shape]
+        F, df = self.num_filters, self.data_format
+        self.analysis_transform = self.analysis_transform_class(F, data_format=df)
+        self.synthesis_transform = self.synthesis_transform_class(F, data_format=df)
+        self.hyper_analysis_transform = self.hyper_analysis_transform_class(F, data_format=df)
+        self.hyper_synthesis_transform = self.hyper_synthesis_transform_class(F, data_format=df)
+        self.init_weights()
+
+    def decompress(self):
+        """Initializes the decompression model (model_types.py:393-411)."""
+        F, df = self.num_filters, self.data_format
+        self.analysis_transform = self.hyper_analysis_transform = None
+        self.synthesis_transform = self.synthesis_transform_class(F, data_format=df)
+        self.hyper_synthesis_transform = self.hyper_synthesis_transform_class(F, data_format=df)
+        self.init_weights()
+
+    # ---- batched graph: x -A-> y -HA-> z -EB-> z_string ; z_hat -HS-> sigma ; (y, sigma) -GC-> y_string ; y_hat -S-> x_hat
+    def _encode_batch(self, ctx, x, debug):
+        B = x.shape[0]
+        F = self.num_filters
+        eb, gc = self.entropy_bottleneck, self.conditional_bottleneck
+        med = self._dev(ctx, 'medians', eb.medians)
+        tab = self._dev(ctx, 'scale_table', gc.scale_table_f32)
+        y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
+        z = self.hyper_analysis_transform.forward_ndhwc(ctx, y)
+        zsym, z_hat = ops.quantize(ctx, z, med, self.round_mode)
+        sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
+        idx = ops.scale_to_index(ctx, sigma, tab)
+        ysym, y_hat = ops.quantize(ctx, y, None, self.round_mode)
+        zsym_h = self._pinned.get('zsym', zsym.shape, torch.int32)
+        ysym_h = self._pinned.get('ysym', ysym.shape, torch.int32)
+        idx_h = self._pinned.get('idx', idx.shape, torch.int32)
+        zsym_h.copy_(zsym, non_blocking=True)
+        ysym_h.copy_(ysym, non_blocking=True)
+        idx_h.copy_(idx, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ctx.device))
+        x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+
+        def finish():
+            ev.synchronize()  # symbols are on the host; the synthesis transform is still running on the GPU
+            zs = ops.range_encode_batch(eb.table, [zsym_h[b] for b in range(B)], None, F, self.coder_threads)
+            ys = ops.range_encode_batch(gc.table, [ysym_h[b] for b in range(B)], [idx_h[b] for b in range(B)], 0,
+                                        self.coder_threads)
+            return list(zip(ys, zs))  # strings = (y_string, z_string), model_types.py:389
+
+        dbg = [None] * B
+        if debug:
+            dbg = [{'z_hat': _np(z_hat[b:b + 1]), 'sigma_hat': _np(sigma[b:b + 1]), 'indexes': _np(idx[b:b + 1]),
+                    'symbols': _np(ysym[b:b + 1]), 'y_hat': _np(y_hat[b:b + 1]), 'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))}
+                   for b in range(B)]
+        return dict(x_hat=x_hat, finish=finish, debug=dbg)
+
+    def _decode_phase_a(self, ctx, strings, dhw):
+        """z_string -EB.decompress-> z_hat -HS-> sigma -> indexes (async D2H)."""
+        B, F = len(strings), self.num_filters
+        eb, gc = self.entropy_bottleneck, self.conditional_bottleneck
+        med = self._dev(ctx, 'medians', eb.medians)
+        tab = self._dev(ctx, 'scale_table', gc.scale_table_f32)
+        zshape = (B, dhw[0] // 16, dhw[1] // 16, dhw[2] // 16, F)
+        zsym_h = torch.empty(zshape, dtype=torch.int32, pin_memory=True)
+        nz = int(np.prod(zshape[1:]))
+        ops.range_decode_batch(eb.table, [s[1] for s in strings], [nz] * B, None, F, self.coder_threads,
+                               out=[zsym_h[b].numpy() for b in range(B)])
+        z_hat = ops.dequantize(ctx, zsym_h.to(ctx.device, non_blocking=True), med)
+        sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
+        idx = ops.scale_to_index(ctx, sigma, tab)
+        idx_h = torch.empty(idx.shape, dtype=torch.int32, pin_memory=True)
+        idx_h.copy_(idx, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ctx.device))
+        return dict(strings=strings, idx_h=idx_h, ev=ev, z_hat=z_hat, sigma=sigma, idx=idx, zsym_h=zsym_h)
+
+    def _decode_phase_b(self, ctx, st, dhw, debug):
+        """(y_string, indexes) -GC.decompress-> y_hat -S-> x_hat."""
+        gc = self.conditional_bottleneck
+        strings, idx_h = st['strings'], st['idx_h']
+        B = len(strings)
+        st['ev'].synchronize()
+        ysym_h = torch.empty(idx_h.shape, dtype=torch.int32, pin_memory=True)
+        n = int(np.prod(idx_h.shape[1:]))
+        ops.range_decode_batch(gc.table, [s[0] for s in strings], [n] * B, [idx_h[b] for b in range(B)], 0,
+                               self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
+        ysym = ysym_h.to(ctx.device, non_blocking=True)
+        y_hat = ops.dequantize(ctx, ysym, None)
+        x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+        dbg = [None] * B
+        if debug:
+            dbg = [{'z_hat': _np(st['z_hat'][b:b + 1]), 'sigma_hat': _np(st['sigma'][b:b + 1]),
+                    'indexes': _np(st['idx'][b:b + 1]), 'symbols': _np(ysym[b:b + 1]), 'y_hat': _np(y_hat[b:b + 1]),
+                    'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))} for b in range(B)]
+        return dict(x_hat=x_hat.contiguous(), debug=dbg)
+
+
+class ModelType(Enum):
+    v1 = CompressionModelV1
+    v2 = CompressionModelV2

@@ -43,6 +43,22 @@ class Context:
             pass
 
 
+_CONTEXTS = {}
+
+
+def get_context(device=None):
+    """Process-wide context cache: one pcc_ctx per GPU."""
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise L.PccError(f'tensor is on {device}: the codec operators only run on the MI355X (no CPU fallback)')
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CONTEXTS:
+        _CONTEXTS[idx] = Context(idx)
+    return _CONTEXTS[idx]
+
+
 class ConvLayer:
     """Weights of one Conv3D / Conv3DTranspose (Keras layouts) + their device images."""
 
