@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- encode+decode throughput of 64^3 voxel blocks (c3p, fixed threshold) on N MI355X.
+
+One step = one pass of the hot path over one batch of 32 synthetic 64^3 occupancy grids per GPU:
+compress graph (analysis, hyper-analysis, quantise, hyper-synthesis, index, quantise, range-encode,
+synthesis, threshold+compaction) + decompress graph (range-decode z, hyper-synthesis, index, range-decode y,
+synthesis, threshold+compaction, points to host).  Inputs are resident in HBM when timing starts.
+
+  python bench.py --gpus 1 --steps 10 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pcc_geo_cnn_v2_amd import ops  # noqa: E402
+from pcc_geo_cnn_v2_amd.model_configs import ModelConfigType  # noqa: E402
+
+RES = 64
+BATCH = 32            # blocks per GPU per step (BASELINE.json configs[1]: "c3p, batch=32 random 64^3 grids")
+CHUNK = 32            # blocks per pipeline chunk (one chunk per step; steps stream through the pipeline)
+FLOPS_PER_BLOCK = 31.086e9   # c3p @64^3, compress 16.562 + decompress 14.524 GFLOP
+PEAK_FP32_MFMA = 157.3       # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+# Synthetic weights (no trained checkpoints exist in the container): Glorot-uniform kernels scaled so that the
+# coded statistics resemble a trained codec at a high-rate point: ~4 % non-zero y symbols (~1.5-2 KB per
+# block), ~5-7 k decoded points per 64^3 block (input: ~5 k points, 2 % occupancy).
+GAIN_ANALYSIS, GAIN_SYNTHESIS, FINAL_BIAS, EB_INIT_SCALE = 1.35, 1.8, 0.0, 0.2
+
+
+def synthetic_weights(model, seed=42):
+    from pcc_geo_cnn_v2_amd.entropy_models import EntropyBottleneck
+    w = {k: v for k, v in model.get_weights().items() if not k.startswith('entropy_bottleneck/')}
+    rng = np.random.default_rng(seed + 1)
+    for k in list(w):
+        if k.endswith('/kernel'):
+            g = GAIN_ANALYSIS if k.startswith(('analysis/', 'hyper_')) else GAIN_SYNTHESIS
+            w[k] = (w[k] * g).astype(np.float32)
+        elif k.endswith('/bias'):
+            w[k] = rng.normal(0, 0.05, w[k].shape).astype(np.float32)
+    last = max(int(k.split('/')[1]) for k in w if k.startswith('synthesis/'))
+    w[f'synthesis/{last}/bias'] = np.array([FINAL_BIAS], np.float32)
+    # factorized prior: a fixed narrow table (an untrained tfc init_scale=10 prior would spend 5 bits on every z)
+    for k, v in EntropyBottleneck.init_params(model.num_filters, init_scale=EB_INIT_SCALE, seed=seed).items():
+        w[f'entropy_bottleneck/{k}'] = v
+    return w
+
+
+def synthetic_blocks(n, device, seed0):
+    """Surface-like occupancy: thin shells of a seeded smooth random field (~1.5-3 % occupancy) -- SURVEY.md §8d."""
+    out = torch.empty((n, RES, RES, RES), dtype=torch.float32, device=device)
+    ax = torch.arange(RES, dtype=torch.float32, device=device)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing='ij')
+    for i in range(n):
+        g = torch.Generator(device='cpu').manual_seed(1234 + seed0 + i)
+        field = torch.zeros((RES, RES, RES), device=device)
+        for _ in range(4):
+            c = (torch.rand(3, generator=g) * RES).to(device)
+            r = float(torch.rand(1, generator=g)) * 20 + 8
+            field += torch.exp(-((gx - c[0]) ** 2 + (gy - c[1]) ** 2 + (gz - c[2]) ** 2) / (2 * r * r))
+        level = float(torch.quantile(field.flatten()[::64], 0.6))
+        out[i] = ((field - level).abs() < 0.012).float()
+    return out
+
+
+def cpu_baseline(model, w, blocks_np, budget_s=12.0):
+    """The oracle's PyTorch-CPU port of the reference's batch-1 per-block loop, on the host cores."""
+    from oracle import oracle as O
+    from oracle import torch_oracle as T
+    eb, gc = model.entropy_bottleneck, model.conditional_bottleneck
+    om = dict(config='c3p', params=w, round_mode=0,
+              eb=dict(cdf=eb.quantized_cdf, cdf_size=eb.cdf_length, offset=eb.offset, medians=eb.medians),
+              gc=(gc.quantized_cdf, gc.cdf_length, gc.offset), scale_table=gc.scale_table_f32)
+    T.codec_block_roundtrip(om, blocks_np[0][None, ..., None])  # warm-up (oneDNN primitive creation)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        T.codec_block_roundtrip(om, blocks_np[n % len(blocks_np)][None, ..., None])
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 2) or n >= 64:
+            break
+    return dict(value=n / el, unit='blocks/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} c3p 64^3 blocks, batch 1 (model_types.py:192-198 loop), oracle/torch_oracle.py: '
+                       f'PyTorch-CPU oneDNN fp32 convs + C range coder, {el:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--chunk', type=int, default=CHUNK)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == max(args.gpus, 1) or world == 1, f'--gpus {args.gpus} but WORLD_SIZE {world}'
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    ctx = ops.get_context(device)
+
+    model = ModelConfigType['c3p'].build(batch_size=args.chunk)
+    model.compress([1, 1, RES, RES, RES])
+    w = synthetic_weights(model)
+    model.set_weights(w)
+
+    # every rank codes its own shard of independent blocks (weak scaling: BATCH blocks per GPU per step)
+    x = synthetic_blocks(BATCH, device, seed0=rank * BATCH)
+    chunks = [x[i:i + args.chunk].contiguous() for i in range(0, BATCH, args.chunk)]
+
+    def run(steps):
+        n_pts, n_bytes, n_blocks = 0, 0, 0
+        for strings, cnt_e, pts in model.roundtrip_stream(ctx, (c for _ in range(steps) for c in chunks)):
+            n_blocks += len(strings)
+            n_bytes += sum(len(s) for ss in strings for s in ss)
+            n_pts += sum(len(p) for p in pts)
+        return n_blocks, n_bytes, n_pts
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    run(max(args.warmup, 0)) if args.warmup > 0 else None
+
+    # live HIP-event timing of the dominant kernel (Conv3DTranspose 16->16 k3 s1 @64^3, 47 % of all MACs)
+    ops.PROFILE = {'match': lambda layer, shp: layer.cin == 16 and layer.cout == 16 and layer.k == 3 and shp[1] == RES,
+                   'events': []}
+    barrier()
+    t0 = time.perf_counter()
+    n_blocks, n_bytes, n_pts = run(args.steps)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    ev = ops.PROFILE['events']
+    ops.PROFILE = None
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        stats = torch.tensor([n_blocks, n_bytes, n_pts], dtype=torch.float64, device=device)
+        dist.all_reduce(stats)  # the one collective of the sharded path: totals to rank 0
+        tot_blocks = int(stats[0].item())
+    else:
+        tot_blocks = n_blocks
+    assert n_blocks == args.steps * BATCH
+
+    if rank == 0:
+        value = tot_blocks / elapsed
+        flops_launch = 2.0 * args.chunk * RES ** 3 * 27 * 16 * 16     # algorithmic flops of one dominant launch
+        avg_ms = float(np.mean(kern_ms)) if kern_ms else float('nan')
+        achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        prof = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
+        if os.path.exists(prof):
+            traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+        out = {
+            'metric': 'voxel_blocks_64cubed_per_sec_encode_decode', 'value': value, 'unit': 'blocks/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'c3p, lambda-independent graph, batch=32 synthetic 64^3 occupancy grids per GPU, '
+                                   'fixed threshold idx 128, encode+decode (BASELINE.json configs[1])',
+                       'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'sharding': f'blocks x{world}',
+                       'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
+                       'bytes_per_block': n_bytes / n_blocks, 'decoded_points_per_block': n_pts / n_blocks,
+                       'conv_tflops_whole_step': value * FLOPS_PER_BLOCK / 1e12,
+                       'conv_frac_of_fp32_mfma_peak_whole_step': value * FLOPS_PER_BLOCK / 1e12 / (PEAK_FP32_MFMA * world)},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_kernel<16,16,3,1,...> (Conv3DTranspose 16->16 k3 s1 @64^3)',
+                         'achieved': achieved, 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA,
+                         'traffic': traffic, 'flops_per_launch': flops_launch, 'avg_launch_ms': avg_ms,
+                         'launches_timed': len(kern_ms)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model, w, x[:4].cpu().numpy())
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -46,6 +46,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Importing torch first makes
+    # our library bind to that already-loaded runtime, so the process has ONE HIP runtime and our kernels
+    # share torch's device context, streams and allocations.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PccError(f'{LIB_PATH} is missing: build it with `make -C pcc_geo_cnn_v2_amd/csrc` '
                        '(python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.')

@@ -192,13 +192,15 @@ class CompressionModel:
             self.set_weights({k: f[k] for k in f.files})
 
     # ------------------------------------------------------------------ block loops
-    def compress_blocks(self, sess, blocks, binstr, points, resolution, level, with_normals=False,
-                        opt_metrics=('d1_mse',), max_deltas=(np.inf,), fixed_threshold=False, debug=False):
-        """Uses the compression model to compress a point cloud (model_types.py:184-218)."""
+    def encode_block_range(self, sess, blocks, resolution, with_normals=False, opt_metrics=('d1_mse',),
+                           max_deltas=(np.inf,), fixed_threshold=False, debug=False):
+        """The per-block part of compress_blocks (model_types.py:192-212) for a list of blocks: returns
+        (strings per block, best-threshold list per block, candidate point lists per block, metric names,
+        debug).  This is the unit that shards across GPUs (sharding.py)."""
         ctx = self._ctx(sess)
         dhw = self._spatial(self.x_shape)
         strings_list, threshold_list, debug_t_list, x_hat_list = [], [], [], []
-        opt_metrics_ret = None
+        opt_metrics_ret = [f'{m}_{d}' for d in max_deltas for m in opt_metrics]
         half = len(self.thresholds) // 2
         for c0 in range(0, len(blocks), self.batch_size):
             chunk = blocks[c0:c0 + self.batch_size]
@@ -208,7 +210,6 @@ class CompressionModel:
             if fixed_threshold:
                 # compute_optimal_thresholds' fixed branch (model_opt.py:27-31): index len//2 for every metric
                 n_m = len(max_deltas) * len(opt_metrics)
-                opt_metrics_ret = [f'{m}_{d}' for d in max_deltas for m in opt_metrics]
                 xyz, counts = self._extract_points(ctx, x_hat, [half] * len(chunk), clip=True)
                 strings = enc['finish']()
                 pts = self._gather_points(xyz, counts)
@@ -227,6 +228,24 @@ class CompressionModel:
                     x_hat_list.append([np.argwhere(xh[j] > self._thr32(t)).astype(np.float32) for t in best])
             strings_list.extend(strings)
             debug_t_list.extend(enc['debug'])
+        return strings_list, threshold_list, x_hat_list, opt_metrics_ret, debug_t_list
+
+    def compress_blocks(self, sess, blocks, binstr, points, resolution, level, with_normals=False,
+                        opt_metrics=('d1_mse',), max_deltas=(np.inf,), fixed_threshold=False, debug=False):
+        """Uses the compression model to compress a point cloud (model_types.py:184-218).  Under
+        torch.distributed (one process per GPU) the block list is sharded and gathered (sharding.py)."""
+        from . import sharding
+        rank, world = sharding.world_info()
+        lo, hi = sharding.shard_range(len(blocks), rank, world)
+        local = self.encode_block_range(sess, blocks[lo:hi], resolution, with_normals, opt_metrics, max_deltas,
+                                        fixed_threshold, debug)
+        strings_list, threshold_list, x_hat_list, debug_t_list, opt_metrics_ret = [], [], [], [], None
+        for s, t, x, names, dbg in sharding.gather_objects(local):
+            strings_list.extend(s)
+            threshold_list.extend(t)
+            x_hat_list.extend(x)
+            debug_t_list.extend(dbg)
+            opt_metrics_ret = opt_metrics_ret or names
         # block -> opt metric to opt metric -> block
         threshold_list = list(zip(*threshold_list))
         x_hat_list = list(zip(*x_hat_list))
@@ -234,9 +253,59 @@ class CompressionModel:
         data_list = [list(zip(strings_list, threshold_list[x['idx']])) for x in metadata]
         return data_list, metadata, debug_t_list
 
+    def roundtrip_stream(self, sess, dense_chunks, thr_idx=None, gather=True):
+        """Streams chunks of dense occupancy grids (each (b,D,H,W) float32 on the GPU) through the compress
+        graph and the decompress graph with fixed-threshold extraction on both sides -- the unit of work of
+        SURVEY.md §8d -- as a 3-deep software pipeline:
+            chunk k   : GPU analysis/hyper + synthesis(enc) | host range-encode + z-decode
+            chunk k-1 : host y-decode | GPU synthesis(dec)
+            chunk k-2 : decoded points gathered to the host
+        Yields (strings, enc_counts, dec_points or dec_counts) per chunk, in order."""
+        ctx = self._ctx(sess)
+        thr_idx = len(self.thresholds) // 2 if thr_idx is None else thr_idx
+        q_b, q_g = [], []
+
+        def stage_b(item):
+            strings, cnt_e, st, dhw, B = item
+            dec = self._decode_phase_b(ctx, st, dhw, False)
+            xyz_d, cnt_d = self._extract_points(ctx, dec['x_hat'], [thr_idx] * B, clip=False)
+            return strings, cnt_e, xyz_d, cnt_d
+
+        def stage_g(item):
+            strings, cnt_e, xyz_d, cnt_d = item
+            pts = self._gather_points(xyz_d, cnt_d) if gather else cnt_d.cpu().numpy()
+            return strings, cnt_e.cpu().numpy(), pts
+
+        for x in dense_chunks:
+            B, dhw = x.shape[0], tuple(x.shape[1:4])
+            enc = self._encode_batch(ctx, x, False)
+            _, cnt_e = self._extract_points(ctx, enc['x_hat'], [thr_idx] * B, clip=True)
+            strings = enc['finish']()
+            st = self._decode_phase_a(ctx, strings, dhw)
+            q_b.append((strings, cnt_e, st, dhw, B))
+            if len(q_b) > 1:
+                q_g.append(stage_b(q_b.pop(0)))
+            if len(q_g) > 1:
+                yield stage_g(q_g.pop(0))
+        while q_b:
+            q_g.append(stage_b(q_b.pop(0)))
+        while q_g:
+            yield stage_g(q_g.pop(0))
+
     def decompress_blocks(self, sess, blocks, x_shape, debug=False):
         """Uses the decompression model to decompress a point cloud (model_types.py:220-238).
         Software pipeline over chunks: the host range decoder of chunk k overlaps the synthesis of k-1."""
+        from . import sharding
+        rank, world = sharding.world_info()
+        if world > 1 and not getattr(self, '_in_shard', False):
+            lo, hi = sharding.shard_range(len(blocks), rank, world)
+            self._in_shard = True
+            try:
+                local = self.decompress_blocks(sess, blocks[lo:hi], x_shape, debug)
+            finally:
+                self._in_shard = False
+            parts = sharding.gather_objects(local)
+            return [b for p in parts for b in p[0]], [d for p in parts for d in p[1]]
         ctx = self._ctx(sess)
         dhw = self._spatial(x_shape)
         chunks = [blocks[c0:c0 + self.batch_size] for c0 in range(0, len(blocks), self.batch_size)]

@@ -107,6 +107,11 @@ def conv_out_shape(layer, x_shape):
     return (N, o(D), o(H), o(W), layer.cout)
 
 
+# Optional live profiling of selected conv launches with HIP events on the launch stream (bench.py):
+# PROFILE = {'match': callable(layer, x_shape) -> bool, 'events': [(start, end), ...]}
+PROFILE = None
+
+
 def conv3d(ctx, x, layer, residual=None, flags=0, impl=L.PCC_IMPL_AUTO, out=None, out_coffset=0):
     """x: (N,D,H,W,Cin) float32 contiguous on ctx.device.  Returns (N,OD,OH,OW,Cout)."""
     assert x.dtype == torch.float32 and x.is_contiguous() and x.device == ctx.device and x.dim() == 5
@@ -124,9 +129,16 @@ def conv3d(ctx, x, layer, residual=None, flags=0, impl=L.PCC_IMPL_AUTO, out=None
         assert residual.is_contiguous() and tuple(residual.shape) == tuple(oshape)
     d = layer.desc(N, D, H, W, flags, impl, ocs, out_coffset)
     im = layer.device_images(ctx, d)
+    prof = PROFILE is not None and PROFILE['match'](layer, x.shape)
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(ctx.device))
     rc = L.lib().pcc_conv3d(ctx.handle, C.byref(d), _ptr(x), _ptr(im['w']), _ptr(im['pk']), _ptr(im['b']),
                             _ptr(residual), _ptr(out), ctx.stream)
     L.check(rc, 'pcc_conv3d')
+    if prof:
+        e1.record(torch.cuda.current_stream(ctx.device))
+        PROFILE['events'].append((e0, e1))
     return out
 
 
