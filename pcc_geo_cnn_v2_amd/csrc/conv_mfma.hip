@@ -18,15 +18,34 @@
 //                     stride-1 gather conv on the input grid); all Cin staged at once.
 //   conv_cin1_kernel: Conv3D with Cin = 1 (first layer): k-slots of the MFMA are kernel taps along x.
 //   conv_cout1_kernel: Conv3DTranspose with Cout = 1 (last layer): VALU dot products from an LDS tile.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// Raw buffer resources: the hardware range check returns 0 for offsets >= num_records, which implements the
+// SAME zero padding (and the tile overhang) without a single branch; the descriptor is wave-uniform (SGPRs).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+constexpr unsigned kOOB = 0x80000000u;                 // >= any per-image byte size the planner admits
+// sched_barrier mask: VALU, SALU, DS and transcendental ops may cross; vector-memory ops and MFMAs may not ->
+// a prefetch load stays in front of the MFMAs of the tap it was written in (two taps before its use).
+#define PCC_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x786)
+// stricter: only VALU / SALU / transcendental ops may cross (memory ops and MFMAs keep their written order)
+#define PCC_PIN_MEM_MFMA() __builtin_amdgcn_sched_barrier(0x406)
 
 struct ConvArgs {
     const float* in;
@@ -113,12 +132,21 @@ conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int ct = 0; ct < C::NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.w) + lane;
     const float* inb = a.in + (size_t)n * a.D * a.H * a.W * CIN;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)a.D * a.H * a.W * CIN * 4u);
+    constexpr int NTAP = KS * KS * KS;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(C::NG * NTAP * C::NCT) * 1024u);
+    const unsigned wlane = lane * 16;
+    // weights: RING-deep register prefetch ring over the linear (g, tap) sequence; the loads are pinned
+    // two taps ahead of their use (>= 1000 cycles of MFMA work) so L2 latency never reaches the MFMA pipe.
+    constexpr int RING = (KS == 3) ? 3 : 5;
+    constexpr int SLAB = (KS == 3) ? NTAP : KS * KS;   // taps unrolled per dynamic iteration
+    static_assert(SLAB % RING == 0, "ring phase must be static");
+    const int q_last = C::NG * NTAP - 1;
 
 #pragma unroll 1
     for (int g = 0; g < C::NG; ++g) {
-        // ---- stage 16 channels of the haloed input tile (zero fill = SAME padding)
+        // ---- stage 16 channels of the haloed input tile (hardware zero fill = SAME padding)
         f32x4 stg[C::ITEMS];
 #pragma unroll
         for (int it = 0; it < C::ITEMS; ++it) {
@@ -128,9 +156,15 @@ conv_fwd_kernel(ConvArgs a) {
             const int ly = rem / C::LX, lx = rem - ly * C::LX;
             const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
             const bool ok = (item < C::NV * 4) && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ok) val = *reinterpret_cast<const f32x4*>(inb + (((size_t)gz * a.H + gy) * a.W + gx) * CIN + g * 16 + q * 4);
-            stg[it] = val;
+            const unsigned off = (unsigned)(((gz * a.H + gy) * a.W + gx) * CIN + g * 16 + q * 4) * 4u;
+            stg[it] = buf_load4(rin, ok ? off : kOOB, 0);
+        }
+        f32x4 wf[RING][C::NCT];
+#pragma unroll
+        for (int r = 0; r < RING - 1; ++r) {
+            const int q = min(g * NTAP + r, q_last);
+#pragma unroll
+            for (int ct = 0; ct < C::NCT; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct) * 1024u);
         }
         if (g > 0) __syncthreads();  // all waves finished reading the previous group
 #pragma unroll
@@ -140,29 +174,60 @@ conv_fwd_kernel(ConvArgs a) {
         }
         __syncthreads();
 
-        const f32x4* wg = wp + (size_t)g * (KS * KS * KS) * C::NCT * 64;
+        auto tap_off = [](int kz, int ky, int kx) { return ((kz * C::LY + ky) * C::LX + kx) * C::VS; };
+        if constexpr (KS == 3) {
+            // B operands (LDS rows) are double-buffered in registers one tap ahead of the MFMAs that use them;
+            // the two sched_barriers keep [prefetch loads | MFMAs] in the written order.
+            f32x4 bb[2][R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) bb[0][i] = *reinterpret_cast<const f32x4*>(lbase + i * ROW_OFF);
+#pragma unroll
+            for (int ts = 0; ts < NTAP; ++ts) {
+                {
+                    const int q = min(g * NTAP + ts + RING - 1, q_last);
+#pragma unroll
+                    for (int ct = 0; ct < C::NCT; ++ct)
+                        wf[(ts + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct) * 1024u);
+                    const int tn = (ts + 1 < NTAP) ? ts + 1 : ts;   // last tap: harmless re-read
+                    const int toff = tap_off(tn / 9, (tn / 3) % 3, tn % 3);
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+                        bb[(ts + 1) & 1][i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
+                    PCC_PIN_MEM_MFMA();
+                }
+                // k-slot quarter j outermost: consecutive MFMAs go to different accumulators (the 40-cycle
+                // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int ct = 0; ct < C::NCT; ++ct)
+                            acc[i][ct] = mfma16(wf[ts % RING][ct][j], bb[ts & 1][i][j], acc[i][ct]);
+                PCC_PIN_MEM_MFMA();
+            }
+        } else {
 #pragma unroll 1
-        for (int kz = 0; kz < KS; ++kz) {
+            for (int sl = 0; sl < NTAP / SLAB; ++sl) {
 #pragma unroll
-            for (int ky = 0; ky < KS; ++ky) {
+                for (int ts = 0; ts < SLAB; ++ts) {
+                    const int t = sl * SLAB + ts;
+                    const int q = min(g * NTAP + t + RING - 1, q_last);
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    const int tap = (kz * KS + ky) * KS + kx;
-                    f32x4 wf[C::NCT];
+                    for (int ct = 0; ct < C::NCT; ++ct)
+                        wf[(ts + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct) * 1024u);
+                    PCC_PIN_VMEM();
+                    const int toff = tap_off(sl, ts / KS, ts % KS);
+                    f32x4 b[R];
 #pragma unroll
-                    for (int ct = 0; ct < C::NCT; ++ct) wf[ct] = wg[(size_t)(tap * C::NCT + ct) * 64];
-                    const int toff = ((kz * C::LY + ky) * C::LX + kx) * C::VS;
+                    for (int i = 0; i < R; ++i) b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
 #pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int ct = 0; ct < C::NCT; ++ct) {
-                            acc[i][ct] = mfma16(wf[ct].x, b.x, acc[i][ct]);
-                            acc[i][ct] = mfma16(wf[ct].y, b.y, acc[i][ct]);
-                            acc[i][ct] = mfma16(wf[ct].z, b.z, acc[i][ct]);
-                            acc[i][ct] = mfma16(wf[ct].w, b.w, acc[i][ct]);
-                        }
-                    }
+                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                            for (int ct = 0; ct < C::NCT; ++ct)
+                                acc[i][ct] = mfma16(wf[ts % RING][ct][j], b[i][j], acc[i][ct]);
                 }
             }
         }
@@ -179,6 +244,209 @@ conv_fwd_kernel(ConvArgs a) {
             for (int ct = 0; ct < C::NCT; ++ct) store_out(a, acc[i][ct], vox, ct * 16 + cq * 4, COUT);
         }
     }
+}
+
+// =====================================================================================================
+// Persistent 16 -> 16, k3, stride 1 kernel (the dominant layer shape: Conv3DTranspose 16->16 @64^3 is 47 % of
+// all c3p MACs).  One workgroup per CU walks tiles g, g+G, ...:
+//   * all 27 weight fragments live in registers for the lifetime of the workgroup (108 VGPRs) -> no weight
+//     traffic and no vmcnt coupling inside the tap loop;
+//   * the haloed input tile is double-buffered in LDS: the global loads of tile i+1 (and the residual of
+//     tile i) are issued BEFORE the 432 MFMAs of tile i and land under them;
+//   * one barrier per tile.
+// Accumulation order per output element is identical to conv_fwd_kernel (tap-major, 4 k-slots): results are
+// bit-identical between the two kernels.
+// =====================================================================================================
+template <int TZ, int TY, int R>
+struct P16Cfg {
+    static constexpr int CIN = 16, COUT = 16, KS = 3;
+    static constexpr int NW = TZ * (TY / R);
+    static constexpr int NT = NW * 64;
+    static constexpr int LZ = TZ + 2, LY = TY + 2, LX = 18;
+    static constexpr int VS = 24;
+    static constexpr int NV = LZ * LY * LX;
+    static constexpr int ITEMS = (NV * 4 + NT - 1) / NT;
+    static constexpr int BUF = ITEMS * NT / 4 * VS;   // floats per LDS buffer (rounded up: no store guards)
+    static constexpr int LDS_BYTES = 2 * BUF * 4;
+    static_assert(ITEMS + R <= 27, "prefetch is spread over the 27 tap sections");
+};
+
+template <int TZ, int TY, int R>
+__global__ void __launch_bounds__((P16Cfg<TZ, TY, R>::NT)) conv16_pers_kernel(ConvArgs a, int ntiles) {
+    using C = P16Cfg<TZ, TY, R>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int v = lane & 15, cq = lane >> 4;
+    const int G = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, G);
+    if (tile >= ntiles) return;
+
+    const int w_yg = wave % (TY / R), w_z = wave / (TY / R);
+    const int ly0 = w_yg * R;
+    const int lane_off = ((w_z * C::LY + ly0) * C::LX + v) * C::VS + cq * 4;
+    constexpr int ROW_OFF = C::LX * C::VS;
+
+    // ---- all weights -> registers
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, 27u * 1024u);
+    f32x4 wreg[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wreg[t] = buf_load4(rw, lane * 16, t * 1024u);
+
+    // ---- per-thread staging items: fixed (lz,ly,lx,quarter) -> relative byte offset inside an image, LDS slot
+    const unsigned img_bytes = (unsigned)a.D * a.H * a.W * 64u;     // 16 channels x 4 B per voxel, in == out size
+    unsigned rel[C::ITEMS];      // byte offset relative to the tile's (z-1, y-1, x-1) corner voxel
+    unsigned lyx[C::ITEMS];      // ly | lx << 8 (for the y/x range test; z is covered by the buffer range check)
+#pragma unroll
+    for (int it = 0; it < C::ITEMS; ++it) {
+        const int item = it * C::NT + tid;
+        const int u = item >> 2, q = item & 3;
+        const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
+        const int ly = rem / C::LX, lx = rem - ly * C::LX;
+        rel[it] = (unsigned)(((lz * a.H + ly) * a.W + lx) * 16 + q * 4) * 4u;
+        lyx[it] = (item < C::NV * 4) ? (unsigned)(ly | (lx << 8)) : 0xFFFFu;   // tail items: lx = 255 -> always out of range
+    }
+
+    // tile coordinates, advanced incrementally by G tiles per iteration (mixed radix, no divisions in the loop)
+    int tx = tile % a.ntx, ty = (tile / a.ntx) % a.nty, tz = (tile / (a.ntx * a.nty)) % a.ntz, n = tile / (a.ntx * a.nty * a.ntz);
+    const int gx_ = G % a.ntx, gy_ = (G / a.ntx) % a.nty, gz_ = (G / (a.ntx * a.nty)) % a.ntz, gn_ = G / (a.ntx * a.nty * a.ntz);
+
+    struct Prefetch { __amdgpu_buffer_rsrc_t rin; unsigned base; int ylo, ny1, xlo, nx1; };
+    auto setup = [&](int n_, int tz_, int ty_, int tx_) {
+        Prefetch p;
+        p.rin = make_rsrc(a.in + (size_t)n_ * a.D * a.H * a.W * 16, img_bytes);
+        const int oz0 = tz_ * TZ, oy0 = ty_ * TY, ox0 = tx_ * 16;
+        p.base = (unsigned)((((oz0 - 1) * a.H + (oy0 - 1)) * a.W + (ox0 - 1)) * 64);   // may wrap: unsigned arithmetic
+        p.ylo = oy0 == 0 ? 1 : 0;                                   // valid local rows:    ylo <= ly <= ylo + ny1
+        p.ny1 = min(C::LY, a.H - oy0 + 1) - p.ylo - 1;
+        p.xlo = ox0 == 0 ? 1 : 0;                                   // valid local columns: xlo <= lx <= xlo + nx1
+        p.nx1 = min(C::LX, a.W - ox0 + 1) - p.xlo - 1;
+        return p;
+    };
+    auto load_item = [&](const Prefetch& p, int it) {
+        // pure-VALU range test: a negative term sets the sign bit, and the sign bit IS the out-of-range offset.
+        // z below 0 wraps to a huge offset, z >= D runs past the image: both hit the hardware range check.
+        const int dy = (int)(lyx[it] & 0xFFu) - p.ylo, dx = (int)(lyx[it] >> 8) - p.xlo;
+        const unsigned neg = (unsigned)(dy | (p.ny1 - dy) | dx | (p.nx1 - dx)) & kOOB;
+        return buf_load4(p.rin, (p.base + rel[it]) | neg, 0);
+    };
+    auto commit = [&](float* buf, const f32x4 (&stg)[C::ITEMS]) {
+#pragma unroll
+        for (int it = 0; it < C::ITEMS; ++it) {
+            const int item = it * C::NT + tid;
+            *reinterpret_cast<f32x4*>(buf + (item >> 2) * C::VS + (item & 3) * 4) = stg[it];
+        }
+    };
+
+    f32x4 stg[C::ITEMS];
+    {
+        const Prefetch p = setup(n, tz, ty, tx);
+#pragma unroll
+        for (int it = 0; it < C::ITEMS; ++it) stg[it] = load_item(p, it);
+    }
+    commit(lds, stg);
+    __syncthreads();
+    int cur = 0;
+    const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
+    const unsigned out_img_bytes = (unsigned)a.OD * a.OH * a.OW * (unsigned)a.ocs * 4u;
+    const f32x4 bias4 = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wr_off = (tid >> 2) * C::VS + (tid & 3) * 4;      // LDS slot of this thread's staging item 0
+    constexpr int WR_STRIDE = (C::NT / 4) * C::VS;               // floats between consecutive items
+    constexpr int COMMIT_LAG = 14;                               // item k is loaded in tap k and written in tap k + LAG
+    static_assert(C::ITEMS + COMMIT_LAG <= 27, "commit must fit in the tap loop");
+
+    // deferred epilogue state of the PREVIOUS tile (its stores are issued inside this tile's tap loop)
+    f32x4 pacc[R], pres[R];
+    unsigned poff[R];                 // byte offset inside the output image, or kOOB (store dropped by hardware)
+    __amdgpu_buffer_rsrc_t prout = make_rsrc(a.out, 0u);
+#pragma unroll
+    for (int i = 0; i < R; ++i) { pacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; pres[i] = pacc[i]; poff[i] = kOOB; }
+
+    auto finish_row = [&](const f32x4& accv, const f32x4& resv_, unsigned off, __amdgpu_buffer_rsrc_t ro) {
+        f32x4 o = accv + bias4;
+        if (a.flags & PCC_CONV_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        o += resv_;   // zeros when PCC_CONV_ADD is clear
+        if (a.flags & PCC_CONV_CLIP01) {
+            o.x = fminf(fmaxf(o.x, 0.f), 1.f); o.y = fminf(fmaxf(o.y, 0.f), 1.f);
+            o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, (int)off, 0, 0);
+    };
+
+    for (;;) {
+        const int next = tile + G;
+        const bool has_next = next < ntiles;
+        int ntx_ = tx + gx_, nty_ = ty + gy_, ntz_ = tz + gz_, nn_ = n + gn_;
+        if (ntx_ >= a.ntx) { ntx_ -= a.ntx; ++nty_; }
+        if (nty_ >= a.nty) { nty_ -= a.nty; ++ntz_; }
+        if (ntz_ >= a.ntz) { ntz_ -= a.ntz; ++nn_; }
+        const Prefetch pn = has_next ? setup(nn_, ntz_, nty_, ntx_) : setup(n, tz, ty, tx);   // no next: harmless re-read
+        const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+        const int gz = oz0 + w_z, gx = ox0 + v;
+        const unsigned lvox0 = (unsigned)((gz * a.OH + oy0 + ly0) * a.OW + gx);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + (size_t)n * a.OD * a.OH * a.OW * 16 : a.in, has_res ? img_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + (size_t)n * a.OD * a.OH * a.OW * a.ocs, out_img_bytes);
+        const bool col_ok = gz < a.OD && gx < a.OW;
+        f32x4 resv[R];
+
+        const float* lbase = lds + cur * C::BUF + lane_off;
+        float* wbase = lds + (cur ^ 1) * C::BUF + wr_off;
+        f32x4 acc[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 bb[2][R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) bb[0][i] = *reinterpret_cast<const f32x4*>(lbase + i * ROW_OFF);
+#pragma unroll
+        for (int ts = 0; ts < 27; ++ts) {
+            // Everything that is not an MFMA is spread over the 27 tap sections and interleaved with the 16 MFMAs
+            // of the section (sched_group_barrier below), so the matrix pipe never waits for the issue of:
+            //   rows of tap ts+1 (4 ds_read) | staging load k of the NEXT tile (ts = k < ITEMS) and its LDS commit
+            //   (ts = k + LAG) | residual load of THIS tile (ts = ITEMS..ITEMS+R-1) | the epilogue row of the PREVIOUS
+            //   tile (ts = 27-R..26, branch-free buffer store).
+            const int tn = (ts + 1 < 27) ? ts + 1 : ts;
+            const int toff = (((tn / 9) * C::LY + (tn / 3) % 3) * C::LX + tn % 3) * C::VS;
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                bb[(ts + 1) & 1][i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
+            if (ts < C::ITEMS) stg[ts] = load_item(pn, ts);
+            if (ts >= COMMIT_LAG && ts < C::ITEMS + COMMIT_LAG)
+                *reinterpret_cast<f32x4*>(wbase + (ts - COMMIT_LAG) * WR_STRIDE) = stg[ts - COMMIT_LAG];
+            if (ts >= C::ITEMS && ts < C::ITEMS + R) {
+                const int i = ts - C::ITEMS;
+                const bool ok = col_ok && (oy0 + ly0 + i) < a.OH && has_res;
+                resv[i] = buf_load4(rres, ok ? ((lvox0 + (unsigned)(i * a.OW)) * 16 + cq * 4) * 4u : kOOB, 0);
+            }
+            if (ts >= 27 - R) finish_row(pacc[ts - (27 - R)], pres[ts - (27 - R)], poff[ts - (27 - R)], prout);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[i] = mfma16(wreg[ts][j], bb[ts & 1][i][j], acc[i]);
+            // issue order inside the section: 1 LDS read, 4 MFMA, ... (VMEM / LDS write / VALU wherever they fit)
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
+            }
+            PCC_PIN_MEM_MFMA();
+        }
+
+        // hand the finished accumulators over to the deferred epilogue of the next iteration
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            pacc[i] = acc[i];
+            pres[i] = resv[i];
+            const bool ok = col_ok && (oy0 + ly0 + i) < a.OH;
+            poff[i] = ok ? ((lvox0 + (unsigned)(i * a.OW)) * (unsigned)a.ocs + a.oco + cq * 4) * 4u : kOOB;
+        }
+        prout = rout;
+        if (!has_next) break;
+        __syncthreads();   // every wave's commits of the next tile are in LDS; nobody still reads `cur`
+        cur ^= 1;
+        tile = next; n = nn_; tz = ntz_; ty = nty_; tx = ntx_;
+    }
+    // epilogue of the last tile
+#pragma unroll
+    for (int i = 0; i < R; ++i) finish_row(pacc[i], pres[i], poff[i], prout);
 }
 
 // =====================================================================================================
@@ -235,8 +503,9 @@ conv_tr2_kernel(ConvArgs a) {
     const float* lbase = lds + (((w_z + G::HL) * C::LY + ly0 + G::HL) * C::LX + lx0 + G::HL) * C::VS + cq * 4;
     constexpr int ROW_OFF = C::RY * C::LX * C::VS;
 
-    // ---- stage the whole haloed tile, all channels
+    // ---- stage the whole haloed tile, all channels (buffer loads: out-of-range voxels read as zeros)
     const float* inb = a.in + (size_t)n * a.D * a.H * a.W * CIN;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)a.D * a.H * a.W * CIN * 4u);
 #pragma unroll 1
     for (int it0 = 0; it0 < C::ITEMS; it0 += 8) {
         f32x4 stg[8];
@@ -247,23 +516,33 @@ conv_tr2_kernel(ConvArgs a) {
             const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
             const int ly = rem / C::LX, lx = rem - ly * C::LX;
             const int gz = bz0 - G::HL + lz, gy = by0 - G::HL + ly, gx = bx0 - G::HL + lx;
-            const bool ok = (it0 + k < C::ITEMS) && (item < C::NV * C::Q) && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ok) val = *reinterpret_cast<const f32x4*>(inb + (((size_t)gz * a.H + gy) * a.W + gx) * CIN + q * 4);
-            stg[k] = val;
+            const bool ok = (item < C::NV * C::Q) && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const unsigned off = (unsigned)(((gz * a.H + gy) * a.W + gx) * CIN + q * 4) * 4u;
+            stg[k] = buf_load4(rin, ok ? off : kOOB, 0);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int item = (it0 + k) * C::NT + tid;
             const int u = item / C::Q, q = item - u * C::Q;
-            if ((it0 + k < C::ITEMS) && item < C::NV * C::Q) *reinterpret_cast<f32x4*>(lds + u * C::VS + q * 4) = stg[k];
+            if (item < C::NV * C::Q) *reinterpret_cast<f32x4*>(lds + u * C::VS + q * 4) = stg[k];
         }
     }
+
+    // weights are packed in consumption order [class][tap in class][g][ct]; the whole (class, tap, g) sequence
+    // is unrolled so that a static 3-deep register ring prefetches two units ahead.
+    constexpr int NSEQ = KS * KS * KS * C::NG;
+    constexpr int RING = 3;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(NSEQ * C::NCT) * 1024u);
+    const unsigned wlane = lane * 16;
+    f32x4 wf[RING][C::NCT];
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r)
+#pragma unroll
+        for (int ct = 0; ct < C::NCT; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct) * 1024u);
     __syncthreads();
 
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.w) + lane;
     const int gzb = bz0 + w_z;
-
+    int seq = 0;  // compile-time after unrolling
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz)
 #pragma unroll
@@ -275,33 +554,36 @@ conv_tr2_kernel(ConvArgs a) {
                 for (int i = 0; i < R; ++i)
 #pragma unroll
                     for (int ct = 0; ct < C::NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-                for (int g = 0; g < C::NG; ++g) {
 #pragma unroll
-                    for (int kz = (pz + G::PL) & 1; kz < KS; kz += 2)
+                for (int kz = (pz + G::PL) & 1; kz < KS; kz += 2)
 #pragma unroll
-                        for (int ky = (py + G::PL) & 1; ky < KS; ky += 2)
+                    for (int ky = (py + G::PL) & 1; ky < KS; ky += 2)
 #pragma unroll
-                            for (int kx = (px + G::PL) & 1; kx < KS; kx += 2) {
-                                const int dz = (pz + G::PL - kz) / 2, dy = (py + G::PL - ky) / 2, dx = (px + G::PL - kx) / 2;
-                                const int tap = (kz * KS + ky) * KS + kx;
-                                f32x4 wf[C::NCT];
+                        for (int kx = (px + G::PL) & 1; kx < KS; kx += 2) {
+                            const int dz = (pz + G::PL - kz) / 2, dy = (py + G::PL - ky) / 2, dx = (px + G::PL - kx) / 2;
+                            const int toff = ((dz * C::LY + dy) * C::LX + dx) * C::VS;
 #pragma unroll
-                                for (int ct = 0; ct < C::NCT; ++ct) wf[ct] = wp[(size_t)((tap * C::NG + g) * C::NCT + ct) * 64];
-                                const int toff = ((dz * C::LY + dy) * C::LX + dx) * C::VS;
+                            for (int g = 0; g < C::NG; ++g, ++seq) {
+                                {
+                                    const int qn = (seq + RING - 1 < NSEQ) ? seq + RING - 1 : NSEQ - 1;
 #pragma unroll
-                                for (int i = 0; i < R; ++i) {
-                                    const f32x4 b = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF + g * 16);
-#pragma unroll
-                                    for (int ct = 0; ct < C::NCT; ++ct) {
-                                        acc[i][ct] = mfma16(wf[ct].x, b.x, acc[i][ct]);
-                                        acc[i][ct] = mfma16(wf[ct].y, b.y, acc[i][ct]);
-                                        acc[i][ct] = mfma16(wf[ct].z, b.z, acc[i][ct]);
-                                        acc[i][ct] = mfma16(wf[ct].w, b.w, acc[i][ct]);
-                                    }
+                                    for (int ct = 0; ct < C::NCT; ++ct)
+                                        wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(qn * C::NCT + ct) * 1024u);
+                                    PCC_PIN_VMEM();
                                 }
+                                f32x4 b[R];
+#pragma unroll
+                                for (int i = 0; i < R; ++i)
+                                    b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF + g * 16);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                                        for (int ct = 0; ct < C::NCT; ++ct)
+                                            acc[i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[i][ct]);
                             }
-                }
+                        }
                 // epilogue of this parity class
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -534,6 +816,7 @@ inline int base_w(const pcc_conv_desc* d) {  // x extent of the grid the rows li
 
 Plan make_plan(const pcc_conv_desc* d) {
     Plan p;
+    if ((double)d->D * d->H * d->W * d->Cin * 4.0 >= 2147483648.0) return p;
     const bool out_vec_ok = d->out_cstride == 0 || (d->out_cstride % 4 == 0 && d->out_coffset % 4 == 0);
     const int k = d->k, s = d->stride;
     const bool even = (d->D % 2 == 0) && (d->H % 2 == 0) && (d->W % 2 == 0);
@@ -583,7 +866,7 @@ int launch(KernelT kern, int nt, int lds_bytes, int tiles, const ConvArgs& a, hi
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 template <int CIN, int COUT, int KS, int S>
-int launch_fwd(int tx, ConvArgs a, hipStream_t st) {
+int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
     // tile shapes per row width: (TX, TZ, TY, TXT, R)
 #define PCC_FWD(TX, TZ, TY, TXT, R)                                                                     \
     {                                                                                                   \
@@ -595,6 +878,29 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st) {
     if constexpr (S == 1) {
         if (tx == 16) {
             if constexpr (COUT >= 64) PCC_FWD(16, 2, 4, 16, 2)
+            else if constexpr (COUT == 16 && CIN == 16 && KS == 3) {
+                static const int variant = getenv("PCC_TILE_VARIANT") ? atoi(getenv("PCC_TILE_VARIANT")) : 10;
+                if (variant >= 10) {
+                    using P = P16Cfg<2, 8, 4>;
+                    a.ntz = cdiv(a.OD, 2); a.nty = cdiv(a.OH, 8); a.ntx = cdiv(a.OW, 16);
+                    const int ntiles = a.N * a.ntz * a.nty * a.ntx;
+                    const int grid = ntiles < num_cu ? ntiles : num_cu;
+                    static thread_local bool conf = false;
+                    if (!conf) {
+                        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_pers_kernel<2, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES));
+                        conf = true;
+                    }
+                    hipLaunchKernelGGL((conv16_pers_kernel<2, 8, 4>), dim3(grid), dim3(P::NT), P::LDS_BYTES, st, a, ntiles);
+                    PCC_CHECK_HIP(hipGetLastError());
+                    return PCC_OK;
+                }
+                if (variant == 1) PCC_FWD(16, 1, 8, 16, 2)
+                if (variant == 2) PCC_FWD(16, 2, 4, 16, 2)
+                if (variant == 3) PCC_FWD(16, 4, 8, 16, 4)
+                if (variant == 4) PCC_FWD(16, 2, 8, 16, 2)
+                if (variant == 5) PCC_FWD(16, 1, 16, 16, 4)
+                PCC_FWD(16, 2, 8, 16, 4)
+            }
             else PCC_FWD(16, 2, 8, 16, 4)
         }
         if (tx == 8) PCC_FWD(8, 2, 8, 8, 2)
@@ -674,16 +980,18 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                                 Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
             }
     } else if (p.kind == K_TR2) {
-        // [tap][g][ct][lane][j]
-        for (int kz = 0; kz < k; ++kz) for (int ky = 0; ky < k; ++ky) for (int kx = 0; kx < k; ++kx) {
-            const int tap = (kz * k + ky) * k + kx;
-            for (int g = 0; g < NG; ++g)
-                for (int ct = 0; ct < NCT; ++ct)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j)
-                            pk[((((size_t)tap * NG + g) * NCT + ct) * 64 + lane) * 4 + j] =
-                                Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
-        }
+        // consumption order of conv_tr2_kernel: [parity class (pz,py,px)][taps of the class (kz,ky,kx)][g][ct][lane][j]
+        const int PL = (k - 2) / 2;
+        size_t seq = 0;
+        for (int pz = 0; pz < 2; ++pz) for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px)
+            for (int kz = (pz + PL) & 1; kz < k; kz += 2) for (int ky = (py + PL) & 1; ky < k; ky += 2)
+                for (int kx = (px + PL) & 1; kx < k; kx += 2)
+                    for (int g = 0; g < NG; ++g, ++seq)
+                        for (int ct = 0; ct < NCT; ++ct)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 4; ++j)
+                                    pk[(((seq * NCT) + ct) * 64 + lane) * 4 + j] =
+                                        Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
     } else if (p.kind == K_CIN1) {
         // [kz][ky][kxg][ct][lane] : kx = kxg*4 + (lane>>4) (zero beyond k), cout = ct*16 + (lane&15)
         const int KXG = (k + 3) / 4;
@@ -704,7 +1012,6 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
 
 int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
                     const float* residual, float* out, hipStream_t st) {
-    (void)ctx;
     const Plan p = make_plan(d);
     PCC_REQUIRE(p.kind != K_NONE, "pcc_conv3d_mfma: shape not covered");
     ConvArgs a;
@@ -717,7 +1024,7 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
     a.ntz = a.nty = a.ntx = 0;
     const int ci = d->Cin, co = d->Cout, k = d->k, s = d->stride;
 
-#define PCC_CASE_FWD(CI, CO, K, S) if (ci == CI && co == CO && k == K && fs == S) return launch_fwd<CI, CO, K, S>(p.tx, a, st);
+#define PCC_CASE_FWD(CI, CO, K, S) if (ci == CI && co == CO && k == K && fs == S) return launch_fwd<CI, CO, K, S>(p.tx, a, st, ctx->num_cu);
 #define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st);
     if (p.kind == K_FWD) {
         const int fs = p.flip ? 1 : s;
