@@ -140,8 +140,10 @@ class CompressionModel:
 
     def _extract_points(self, ctx, x_hat, thr_idx, clip):
         """x_hat (B,D,H,W) device; thr_idx list of ints -> list of (n,3) float32 numpy arrays."""
-        B = x_hat.shape[0]
-        thr = torch.from_numpy(np.array([self._thr32(t) for t in thr_idx], np.float32)).to(ctx.device)
+        # cached on the device: a pageable host->device copy here would block the host until the GPU drains
+        # and serialise the pipeline
+        thr = self._dev(ctx, ('thr',) + tuple(int(t) for t in thr_idx),
+                        np.array([self._thr32(t) for t in thr_idx], np.float32))
         xyz, counts = ops.threshold_compact(ctx, x_hat, thr, clip=clip)
         return xyz, counts
 
