@@ -799,9 +799,133 @@ __global__ void __launch_bounds__((Cout1Cfg<CIN, KS, S, TZ, TY, TXT>::NT)) conv_
 }
 
 // =====================================================================================================
+// Conv3DTranspose 16 -> 1, k3, stride 1 (last layer of the V2 synthesis transforms) on the matrix cores.
+//   A GEMV-shaped layer has no N dimension for an implicit GEMM, so the contraction is split:
+//     (1) P[tap][voxel] = sum_c w[tap][c] * in[voxel][c]      -- MFMA: M = 27 taps (2 tiles), N = 16 voxels,
+//         K = 16 channels; every input voxel is read ONCE from global memory (coalesced 1 KiB per wave load);
+//     (2) out[z,y,x] = sum_tap P[tap][voxel + offset(tap)]      -- 27 LDS reads + adds per output voxel.
+//   A workgroup owns a 16 x 16 (y,x) column block of one image and marches along z: input plane p feeds the
+//   three output planes p-1, p, p+1 through rolling accumulators, so there is no z halo at all.
+//   Summation order per output: channels (MFMA chain) -> (ky,kx) -> kz, fixed => deterministic.
+// =====================================================================================================
+struct Cout1M {
+    static constexpr int NT = 256, TYX = 16;
+    static constexpr int LYX = TYX + 2;                 // haloed plane edge
+    static constexpr int NU = 336;                      // 21 N-tiles x 16 voxels >= 18*18 = 324
+    static constexpr int NTILE = NU / 16;
+    static constexpr int LDS_BYTES = 27 * NU * 4;
+    static constexpr int PER_WAVE = (NTILE + 3) / 4;    // N-tiles per wave (6,5,5,5)
+};
+
+__global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
+    using C = Cout1M;
+    extern __shared__ __attribute__((aligned(16))) float P[];   // [27][NU]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int v = lane & 15, cq = lane >> 4;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = t % a.ntx; t /= a.ntx;
+    const int ty = t % a.nty;
+    const int n = t / a.nty;
+    const int y0 = ty * C::TYX, x0 = tx * C::TYX;
+
+    // A operand: w[tap = 16*mt + (lane & 15)][channel 4*(lane>>4) + j], taps >= 27 are zero rows
+    const f32x4 wA0 = *reinterpret_cast<const f32x4*>(a.w + (0 * 64 + lane) * 4);
+    const f32x4 wA1 = *reinterpret_cast<const f32x4*>(a.w + (1 * 64 + lane) * 4);
+
+    // this lane's voxels (one per N-tile it serves): byte offset inside a plane, sign bit set when outside H x W
+    unsigned voff[C::PER_WAVE];
+    int uidx[C::PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < C::PER_WAVE; ++k) {
+        const int nt = wave + 4 * k;
+        const int u = nt * 16 + v;
+        const int ly = u / C::LYX, lx = u - ly * C::LYX;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        const bool ok = nt < C::NTILE && u < C::LYX * C::LYX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        voff[k] = ok ? (unsigned)((gy * a.W + gx) * 16 + cq * 4) * 4u : kOOB;
+        uidx[k] = u;
+    }
+    const unsigned plane_bytes = (unsigned)a.H * a.W * 64u;
+    const float* inb = a.in + (size_t)n * a.D * a.H * a.W * 16;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)a.D * plane_bytes);
+
+    // gather side: thread -> output column (y, x)
+    const int oy = tid >> 4, ox = tid & 15;
+    const bool col_ok = (y0 + oy) < a.OH && (x0 + ox) < a.OW;
+    const float* pcol = P + oy * C::LYX + ox;
+    const float bias = (a.flags & PCC_CONV_BIAS) ? a.bias[0] : 0.f;
+    const size_t out_plane = (size_t)a.OH * a.OW;
+    float* ob = a.out + ((size_t)n * a.OD * out_plane + (size_t)(y0 + oy) * a.OW + x0 + ox) * a.ocs + a.oco;
+    const float* rb = (a.flags & PCC_CONV_ADD) ? a.res + (size_t)n * a.OD * out_plane + (size_t)(y0 + oy) * a.OW + x0 + ox : nullptr;
+
+    auto finish = [&](float s, int z) {
+        s += bias;
+        if (a.flags & PCC_CONV_RELU) s = fmaxf(s, 0.f);
+        if (rb) s += rb[(size_t)z * out_plane];
+        if (a.flags & PCC_CONV_CLIP01) s = fminf(fmaxf(s, 0.f), 1.f);
+        if (col_ok) ob[(size_t)z * out_plane * a.ocs] = s;
+    };
+
+    f32x4 nxt[C::PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = buf_load4(rin, voff[k], 0);
+    float accA = 0.f, accB = 0.f, accC = 0.f;   // outputs z = p+1, p, p-1
+
+#pragma unroll 1
+    for (int p = 0; p < a.D; ++p) {
+        f32x4 cur[C::PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < C::PER_WAVE; ++k) cur[k] = nxt[k];
+        if (p + 1 < a.D) {
+#pragma unroll
+            for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = buf_load4(rin, voff[k], (unsigned)(p + 1) * plane_bytes);
+        }
+        // ---- (1) P = W x in for the haloed plane p
+        f32x4 d0[C::PER_WAVE], d1[C::PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < C::PER_WAVE; ++k) { d0[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; d1[k] = d0[k]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < C::PER_WAVE; ++k) {
+                d0[k] = mfma16(wA0[j], cur[k][j], d0[k]);
+                d1[k] = mfma16(wA1[j], cur[k][j], d1[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < C::PER_WAVE; ++k) {
+            if (wave + 4 * k < C::NTILE) {
+                float* pw = P + uidx[k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pw[(4 * cq + r) * C::NU] = d0[k][r];
+                    if (16 + 4 * cq + r < 27) pw[(16 + 4 * cq + r) * C::NU] = d1[k][r];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- (2) gather: plane p is tap kz = 0 of output p+1, kz = 1 of output p, kz = 2 of output p-1
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* q = pcol + ky * C::LYX + kx;
+                s0 += q[(0 * 9 + ky * 3 + kx) * C::NU];
+                s1 += q[(1 * 9 + ky * 3 + kx) * C::NU];
+                s2 += q[(2 * 9 + ky * 3 + kx) * C::NU];
+            }
+        accA += s0; accB += s1; accC += s2;
+        if (p >= 1) finish(accC, p - 1);
+        accC = accB; accB = accA; accA = 0.f;
+        __syncthreads();
+    }
+    finish(accC, a.D - 1);
+}
+
+// =====================================================================================================
 // host side: kernel selection, launch, weight packing
 // =====================================================================================================
-enum Kind { K_NONE = 0, K_FWD, K_TR2, K_CIN1, K_COUT1 };
+enum Kind { K_NONE = 0, K_FWD, K_TR2, K_CIN1, K_COUT1, K_COUT1M };
 
 struct Plan {
     Kind kind = K_NONE;
@@ -825,7 +949,8 @@ Plan make_plan(const pcc_conv_desc* d) {
         return p;
     }
     if (d->transposed && d->Cout == 1) {
-        if (s == 1 && k == 3 && (d->Cin == 16 || d->Cin == 32) && d->W % 8 == 0) { p.kind = K_COUT1; p.flip = true; }
+        if (s == 1 && k == 3 && d->Cin == 16) { p.kind = K_COUT1M; p.flip = true; }
+        else if (s == 1 && k == 3 && d->Cin == 32 && d->W % 8 == 0) { p.kind = K_COUT1; p.flip = true; }
         else if (s == 2 && k == 9 && d->Cin == 32 && d->W % 8 == 0) p.kind = K_COUT1;
         return p;
     }
@@ -951,6 +1076,7 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
         case K_TR2: return k3 * d->Cin * d->Cout;
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
         case K_COUT1: return k3 * d->Cin;
+        case K_COUT1M: return 2 * 64 * 4;
         default: return 0;
     }
 }
@@ -1002,6 +1128,14 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                     pk[((((size_t)(kz * k + ky) * KXG + kg) * NCT) + ct) * 64 + lane] =
                         kx < k ? Wf(kz, ky, kx, 0, ct * 16 + (lane & 15)) : 0.f;
                 }
+    } else if (p.kind == K_COUT1M) {
+        // [mt][lane][j]: tap = 16*mt + (lane & 15) (zero rows beyond 27), channel = 4*(lane>>4) + j
+        for (int mt = 0; mt < 2; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int tap = 16 * mt + (lane & 15);
+                    pk[(mt * 64 + lane) * 4 + j] = tap < 27 ? Wf(tap / 9, (tap / 3) % 3, tap % 3, 4 * (lane >> 4) + j, 0) : 0.f;
+                }
     } else {  // K_COUT1: [tap][ci]
         for (int kz = 0; kz < k; ++kz) for (int ky = 0; ky < k; ++ky) for (int kx = 0; kx < k; ++kx)
             for (int ci = 0; ci < Cin; ++ci)
@@ -1043,6 +1177,9 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
     }
         PCC_CIN1(16, 3, 2, 8, 4) PCC_CIN1(32, 3, 2, 8, 4) PCC_CIN1(16, 9, 2, 8, 4) PCC_CIN1(32, 9, 2, 8, 4)
 #undef PCC_CIN1
+    } else if (p.kind == K_COUT1M) {
+        a.ntz = 1; a.nty = cdiv(a.H, Cout1M::TYX); a.ntx = cdiv(a.W, Cout1M::TYX);
+        return launch(conv_cout1_mfma_kernel, Cout1M::NT, Cout1M::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
     } else if (p.kind == K_COUT1) {
 #define PCC_COUT1(CI, K, S, TZ, TY, TXT)                                                                \
     if (ci == CI && k == K && s == S) {                                                                 \

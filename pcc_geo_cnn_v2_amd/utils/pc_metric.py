@@ -52,8 +52,11 @@ def compute_metrics(p1, p2, r, p1_n=None, t1=None):
     if t1 is None:
         t1 = cKDTree(p1, balanced_tree=False)
     t2 = cKDTree(p2, balanced_tree=False)
-    _, idx2 = t2.query(p1, workers=-1)
-    _, idx1 = t1.query(p2, workers=-1)
+    # the reference asks for all cores (n_jobs=-1, pc_metric.py:80-81); for the small per-block queries of the
+    # threshold search the thread start-up dominates on many-core hosts, so only large clouds go parallel
+    workers = -1 if max(len(p1), len(p2)) > 200000 else 1
+    _, idx2 = t2.query(p1, workers=workers)
+    _, idx1 = t1.query(p2, workers=workers)
 
     max_energy = 3 * r * r
     p1_ngb = p2[idx2]
