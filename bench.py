@@ -95,8 +95,8 @@ def cpu_baseline(model, w, blocks_np, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--chunk', type=int, default=CHUNK)
     args = ap.parse_args()

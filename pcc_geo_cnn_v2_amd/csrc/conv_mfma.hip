@@ -257,13 +257,13 @@ conv_fwd_kernel(ConvArgs a) {
 // Accumulation order per output element is identical to conv_fwd_kernel (tap-major, 4 k-slots): results are
 // bit-identical between the two kernels.
 // =====================================================================================================
-template <int TZ, int TY, int R>
+template <int TZ, int TY, int R, int VS_>
 struct P16Cfg {
     static constexpr int CIN = 16, COUT = 16, KS = 3;
     static constexpr int NW = TZ * (TY / R);
     static constexpr int NT = NW * 64;
     static constexpr int LZ = TZ + 2, LY = TY + 2, LX = 18;
-    static constexpr int VS = 24;
+    static constexpr int VS = VS_;   // floats per voxel in LDS: 24 = conflict-free, 20 = smaller (some 2-way conflicts)
     static constexpr int NV = LZ * LY * LX;
     static constexpr int ITEMS = (NV * 4 + NT - 1) / NT;
     static constexpr int BUF = ITEMS * NT / 4 * VS;   // floats per LDS buffer (rounded up: no store guards)
@@ -271,9 +271,9 @@ struct P16Cfg {
     static_assert(ITEMS + R <= 27, "prefetch is spread over the 27 tap sections");
 };
 
-template <int TZ, int TY, int R>
-__global__ void __launch_bounds__((P16Cfg<TZ, TY, R>::NT)) conv16_pers_kernel(ConvArgs a, int ntiles) {
-    using C = P16Cfg<TZ, TY, R>;
+template <int TZ, int TY, int R, int VS_, int WGS_PER_CU>
+__global__ void __launch_bounds__((P16Cfg<TZ, TY, R, VS_>::NT), (WGS_PER_CU * P16Cfg<TZ, TY, R, VS_>::NT / 256)) conv16_pers_kernel(ConvArgs a, int ntiles) {
+    using C = P16Cfg<TZ, TY, R, VS_>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v = lane & 15, cq = lane >> 4;
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__((P16Cfg<TZ, TY, R>::NT)) conv16_pers_kernel(Co
     const f32x4 bias4 = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wr_off = (tid >> 2) * C::VS + (tid & 3) * 4;      // LDS slot of this thread's staging item 0
     constexpr int WR_STRIDE = (C::NT / 4) * C::VS;               // floats between consecutive items
-    constexpr int COMMIT_LAG = 14;                               // item k is loaded in tap k and written in tap k + LAG
+    constexpr int COMMIT_LAG = (C::ITEMS + 14 <= 27) ? 14 : 27 - C::ITEMS;                             // item k is loaded in tap k and written in tap k + LAG
     static_assert(C::ITEMS + COMMIT_LAG <= 27, "commit must fit in the tap loop");
 
     // deferred epilogue state of the PREVIOUS tile (its stores are issued inside this tile's tap loop)
@@ -528,20 +528,25 @@ conv_tr2_kernel(ConvArgs a) {
         }
     }
 
-    // weights are packed in consumption order [class][tap in class][g][ct]; the whole (class, tap, g) sequence
-    // is unrolled so that a static 3-deep register ring prefetches two units ahead.
+    // weights are packed in consumption order [class][tap in class][g][ct]
     constexpr int NSEQ = KS * KS * KS * C::NG;
-    constexpr int RING = 3;
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(NSEQ * C::NCT) * 1024u);
     const unsigned wlane = lane * 16;
+    const int gzb = bz0 + w_z;
+    // FULL: the whole (class, tap, g) sequence is unrolled so that a static 3-deep register ring prefetches two
+    // units ahead.  For the widest shape (64 -> 64: 3456 MFMAs per wave) that would not fit the instruction
+    // cache, so the cin-group loop stays dynamic there and the weights are loaded per (tap, group).
+    constexpr bool FULL = C::NG * C::NCT < 16;
+    constexpr int RING = 3;
     f32x4 wf[RING][C::NCT];
+    if constexpr (FULL) {
 #pragma unroll
-    for (int r = 0; r < RING - 1; ++r)
+        for (int r = 0; r < RING - 1; ++r)
 #pragma unroll
-        for (int ct = 0; ct < C::NCT; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct) * 1024u);
+            for (int ct = 0; ct < C::NCT; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct) * 1024u);
+    }
     __syncthreads();
 
-    const int gzb = bz0 + w_z;
     int seq = 0;  // compile-time after unrolling
 #pragma unroll
     for (int pz = 0; pz < 2; ++pz)
@@ -562,26 +567,49 @@ conv_tr2_kernel(ConvArgs a) {
                         for (int kx = (px + G::PL) & 1; kx < KS; kx += 2) {
                             const int dz = (pz + G::PL - kz) / 2, dy = (py + G::PL - ky) / 2, dx = (px + G::PL - kx) / 2;
                             const int toff = ((dz * C::LY + dy) * C::LX + dx) * C::VS;
+                            if constexpr (FULL) {
 #pragma unroll
-                            for (int g = 0; g < C::NG; ++g, ++seq) {
-                                {
-                                    const int qn = (seq + RING - 1 < NSEQ) ? seq + RING - 1 : NSEQ - 1;
-#pragma unroll
-                                    for (int ct = 0; ct < C::NCT; ++ct)
-                                        wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(qn * C::NCT + ct) * 1024u);
-                                    PCC_PIN_VMEM();
-                                }
-                                f32x4 b[R];
-#pragma unroll
-                                for (int i = 0; i < R; ++i)
-                                    b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF + g * 16);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                                    for (int i = 0; i < R; ++i)
+                                for (int g = 0; g < C::NG; ++g, ++seq) {
+                                    {
+                                        const int qn = (seq + RING - 1 < NSEQ) ? seq + RING - 1 : NSEQ - 1;
 #pragma unroll
                                         for (int ct = 0; ct < C::NCT; ++ct)
-                                            acc[i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[i][ct]);
+                                            wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(qn * C::NCT + ct) * 1024u);
+                                        PCC_PIN_VMEM();
+                                    }
+                                    f32x4 b[R];
+#pragma unroll
+                                    for (int i = 0; i < R; ++i)
+                                        b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF + g * 16);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                                            for (int ct = 0; ct < C::NCT; ++ct)
+                                                acc[i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[i][ct]);
+                                }
+                            } else {
+                                const int seq0 = seq;
+                                seq += C::NG;
+#pragma unroll 1
+                                for (int g = 0; g < C::NG; ++g) {
+                                    f32x4 w1[C::NCT];
+#pragma unroll
+                                    for (int ct = 0; ct < C::NCT; ++ct)
+                                        w1[ct] = buf_load4(rw, wlane, (unsigned)((seq0 + g) * C::NCT + ct) * 1024u);
+                                    f32x4 b[R];
+#pragma unroll
+                                    for (int i = 0; i < R; ++i)
+                                        b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF + g * 16);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                                            for (int ct = 0; ct < C::NCT; ++ct)
+                                                acc[i][ct] = mfma16(w1[ct][j], b[i][j], acc[i][ct]);
+                                }
                             }
                         }
                 // epilogue of this parity class
@@ -972,8 +1000,8 @@ Plan make_plan(const pcc_conv_desc* d) {
     return p;
 }
 
-template <typename KernelT>
-int launch(KernelT kern, int nt, int lds_bytes, int tiles, const ConvArgs& a, hipStream_t st) {
+template <typename KernelT, typename... Extra>
+int launch(KernelT kern, int nt, int lds_bytes, int tiles, const ConvArgs& a, hipStream_t st, Extra... extra) {
     static thread_local const void* configured[64];
     static thread_local int nconf = 0;
     bool done = false;
@@ -983,7 +1011,7 @@ int launch(KernelT kern, int nt, int lds_bytes, int tiles, const ConvArgs& a, hi
             PCC_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         if (nconf < 64) configured[nconf++] = (const void*)kern;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(nt), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(nt), lds_bytes, st, a, extra...);
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;
 }
@@ -1004,21 +1032,20 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
         if (tx == 16) {
             if constexpr (COUT >= 64) PCC_FWD(16, 2, 4, 16, 2)
             else if constexpr (COUT == 16 && CIN == 16 && KS == 3) {
-                static const int variant = getenv("PCC_TILE_VARIANT") ? atoi(getenv("PCC_TILE_VARIANT")) : 10;
-                if (variant >= 10) {
-                    using P = P16Cfg<2, 8, 4>;
-                    a.ntz = cdiv(a.OD, 2); a.nty = cdiv(a.OH, 8); a.ntx = cdiv(a.OW, 16);
-                    const int ntiles = a.N * a.ntz * a.nty * a.ntx;
-                    const int grid = ntiles < num_cu ? ntiles : num_cu;
-                    static thread_local bool conf = false;
-                    if (!conf) {
-                        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_pers_kernel<2, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES));
-                        conf = true;
-                    }
-                    hipLaunchKernelGGL((conv16_pers_kernel<2, 8, 4>), dim3(grid), dim3(P::NT), P::LDS_BYTES, st, a, ntiles);
-                    PCC_CHECK_HIP(hipGetLastError());
-                    return PCC_OK;
-                }
+                static const int variant = getenv("PCC_TILE_VARIANT") ? atoi(getenv("PCC_TILE_VARIANT")) : 11;
+#define PCC_P16(TZ, TY, R, VS, WPC)                                                                     \
+    {                                                                                                   \
+        using P = P16Cfg<TZ, TY, R, VS>;                                                                \
+        a.ntz = cdiv(a.OD, TZ); a.nty = cdiv(a.OH, TY); a.ntx = cdiv(a.OW, 16);                         \
+        const int ntiles = a.N * a.ntz * a.nty * a.ntx;                                                 \
+        const int grid = ntiles < num_cu * WPC ? ntiles : num_cu * WPC;                                 \
+        return launch(conv16_pers_kernel<TZ, TY, R, VS, WPC>, P::NT, P::LDS_BYTES, grid, a, st, ntiles); \
+    }
+                if (variant == 10) PCC_P16(2, 8, 4, 24, 1)
+                if (variant == 11) PCC_P16(2, 4, 2, 20, 2)
+                if (variant == 12) PCC_P16(2, 8, 4, 20, 1)
+                if (variant == 13) PCC_P16(2, 4, 2, 24, 1)
+#undef PCC_P16
                 if (variant == 1) PCC_FWD(16, 1, 8, 16, 2)
                 if (variant == 2) PCC_FWD(16, 2, 4, 16, 2)
                 if (variant == 3) PCC_FWD(16, 4, 8, 16, 4)

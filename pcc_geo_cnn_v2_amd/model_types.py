@@ -126,6 +126,27 @@ class CompressionModel:
         assert len(x_shape) == 5
         return tuple(x_shape[2:5]) if self.data_format == 'channels_first' else tuple(x_shape[1:4])
 
+    def _side_stream(self, ctx):
+        if not hasattr(self, '_copy_stream'):
+            self._copy_stream = torch.cuda.Stream(ctx.device)
+        return self._copy_stream
+
+    def _copy_out(self, ctx, pairs):
+        """Device->pinned-host copies on a side stream; returns the event the host has to wait for."""
+        main = torch.cuda.current_stream(ctx.device)
+        if not hasattr(self, '_copy_stream'):
+            self._copy_stream = torch.cuda.Stream(ctx.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            for dst, src in pairs:
+                dst.copy_(src, non_blocking=True)
+                src.record_stream(self._copy_stream)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        return done
+
     def _thr32(self, idx):
         # the reference compares float32 x_hat with a float64 scalar under numpy 1.18 value-based
         # casting, i.e. in float32 (SURVEY.md row T)
@@ -147,11 +168,23 @@ class CompressionModel:
         xyz, counts = ops.threshold_compact(ctx, x_hat, thr, clip=clip)
         return xyz, counts
 
-    @staticmethod
-    def _gather_points(xyz, counts):
-        cnt = counts.cpu().numpy()
-        parts = [xyz[b, :int(cnt[b])] for b in range(len(cnt))]
-        flat = torch.cat(parts).cpu().numpy() if len(parts) else np.zeros((0, 3), np.float32)
+    def _gather_points(self, xyz, counts, ctx=None, ready=None):
+        """Point lists to the host.  When `ready` (an event recorded after the compaction kernels) is given, the
+        copies run on the side stream and wait only for that event, so the host never drains the main queue."""
+        if ready is None or ctx is None:
+            cnt = counts.cpu().numpy()
+            parts = [xyz[b, :int(cnt[b])] for b in range(len(cnt))]
+            flat = torch.cat(parts).cpu().numpy() if len(parts) else np.zeros((0, 3), np.float32)
+        else:
+            if not hasattr(self, '_copy_stream'):
+                self._copy_stream = torch.cuda.Stream(ctx.device)
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(ready)
+                xyz.record_stream(self._copy_stream)
+                counts.record_stream(self._copy_stream)
+                cnt = counts.cpu().numpy()
+                parts = [xyz[b, :int(cnt[b])] for b in range(len(cnt))]
+                flat = torch.cat(parts).cpu().numpy() if len(parts) else np.zeros((0, 3), np.float32)
         out, p = [], 0
         for n in cnt:
             out.append(flat[p:p + int(n)].copy())
@@ -271,12 +304,21 @@ class CompressionModel:
             strings, cnt_e, st, dhw, B = item
             dec = self._decode_phase_b(ctx, st, dhw, False)
             xyz_d, cnt_d = self._extract_points(ctx, dec['x_hat'], [thr_idx] * B, clip=False)
-            return strings, cnt_e, xyz_d, cnt_d
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(ctx.device))
+            return strings, cnt_e, xyz_d, cnt_d, ready
 
         def stage_g(item):
-            strings, cnt_e, xyz_d, cnt_d = item
-            pts = self._gather_points(xyz_d, cnt_d) if gather else cnt_d.cpu().numpy()
-            return strings, cnt_e.cpu().numpy(), pts
+            strings, cnt_e, xyz_d, cnt_d, ready = item
+            pts = self._gather_points(xyz_d, cnt_d, ctx, ready) if gather else None
+            with torch.cuda.stream(self._side_stream(ctx)):     # never a blocking copy on the main stream
+                self._side_stream(ctx).wait_event(ready)
+                cnt_e.record_stream(self._side_stream(ctx))
+                ce = cnt_e.cpu().numpy()
+                if not gather:
+                    cnt_d.record_stream(self._side_stream(ctx))
+                    pts = cnt_d.cpu().numpy()
+            return strings, ce, pts
 
         for x in dense_chunks:
             B, dhw = x.shape[0], tuple(x.shape[1:4])
@@ -391,9 +433,7 @@ class CompressionModelV1(CompressionModel):
         y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
         ysym, y_hat = ops.quantize(ctx, y, med, self.round_mode)
         ysym_h = self._pinned.get('ysym', ysym.shape, torch.int32)
-        ysym_h.copy_(ysym, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(ctx.device))
+        ev = self._copy_out(ctx, [(ysym_h, ysym)])
         x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
 
         def finish():
@@ -505,11 +545,8 @@ class CompressionModelV2(CompressionModel):
         zsym_h = self._pinned.get('zsym', zsym.shape, torch.int32)
         ysym_h = self._pinned.get('ysym', ysym.shape, torch.int32)
         idx_h = self._pinned.get('idx', idx.shape, torch.int32)
-        zsym_h.copy_(zsym, non_blocking=True)
-        ysym_h.copy_(ysym, non_blocking=True)
-        idx_h.copy_(idx, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(ctx.device))
+        # symbols leave on a side stream so that the copies overlap the synthesis transform
+        ev = self._copy_out(ctx, [(zsym_h, zsym), (ysym_h, ysym), (idx_h, idx)])
         x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
 
         def finish():
