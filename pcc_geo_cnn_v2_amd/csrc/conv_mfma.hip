@@ -84,12 +84,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   tile = TZ x TY x TXT output voxels; a "row" = 16 voxels = RY(=16/TX) y-lines x TX voxels along x;
 //   each wave owns R rows that are consecutive in y.
 // =====================================================================================================
-template <int CIN, int COUT, int KS, int S, int TX, int TZ, int TY, int TXT, int R>
+template <int CIN, int COUT, int KS, int S, int TX, int TZ, int TY, int TXT, int R, int CTW = COUT / 16>
 struct FwdCfg {
     static constexpr int NG = CIN / 16, NCT = COUT / 16;
     static constexpr int RY = 16 / TX;
     static constexpr int NYB = TY / RY, NXB = TXT / TX;
-    static constexpr int NW = TZ * (NYB / R) * NXB;
+    static constexpr int NCG = NCT / CTW;              // cout-tile groups: waves also split the output channels
+    static constexpr int NW = TZ * (NYB / R) * NXB * NCG;
     static constexpr int NT = NW * 64;
     static constexpr int PL = (S == 1) ? (KS - 1) / 2 : (KS - 2) / 2;  // SAME pad_low (even input dims for S=2)
     static constexpr int LZ = (TZ - 1) * S + KS, LY = (TY - 1) * S + KS, LX = (TXT - 1) * S + KS;
@@ -100,10 +101,10 @@ struct FwdCfg {
     static_assert(TY % RY == 0 && NYB % R == 0 && TXT % TX == 0, "bad tile");
 };
 
-template <int CIN, int COUT, int KS, int S, int TX, int TZ, int TY, int TXT, int R>
-__global__ void __launch_bounds__((FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R>::NT))
+template <int CIN, int COUT, int KS, int S, int TX, int TZ, int TY, int TXT, int R, int CTW = COUT / 16>
+__global__ void __launch_bounds__((FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW>::NT))
 conv_fwd_kernel(ConvArgs a) {
-    using C = FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R>;
+    using C = FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v = lane & 15, cq = lane >> 4;
@@ -118,6 +119,7 @@ conv_fwd_kernel(ConvArgs a) {
 
     // wave -> (z, y-block group, x-block)
     int wv = wave;
+    const int ct0 = (wv % C::NCG) * CTW; wv /= C::NCG;   // first cout tile of this wave
     const int w_xb = wv % C::NXB; wv /= C::NXB;
     const int w_yg = wv % (C::NYB / R);
     const int w_z = wv / (C::NYB / R);
@@ -126,11 +128,11 @@ conv_fwd_kernel(ConvArgs a) {
     const float* lbase = lds + ((w_z * S * C::LY + ly0 * S) * C::LX + lx0 * S) * C::VS + cq * 4;
     constexpr int ROW_OFF = C::RY * S * C::LX * C::VS;  // floats between consecutive rows of a wave
 
-    f32x4 acc[R][C::NCT];
+    f32x4 acc[R][CTW];
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int ct = 0; ct < C::NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CTW; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const float* inb = a.in + (size_t)n * a.D * a.H * a.W * CIN;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)a.D * a.H * a.W * CIN * 4u);
@@ -159,12 +161,12 @@ conv_fwd_kernel(ConvArgs a) {
             const unsigned off = (unsigned)(((gz * a.H + gy) * a.W + gx) * CIN + g * 16 + q * 4) * 4u;
             stg[it] = buf_load4(rin, ok ? off : kOOB, 0);
         }
-        f32x4 wf[RING][C::NCT];
+        f32x4 wf[RING][CTW];
 #pragma unroll
         for (int r = 0; r < RING - 1; ++r) {
             const int q = min(g * NTAP + r, q_last);
 #pragma unroll
-            for (int ct = 0; ct < C::NCT; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct) * 1024u);
+            for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 1024u);
         }
         if (g > 0) __syncthreads();  // all waves finished reading the previous group
 #pragma unroll
@@ -186,14 +188,13 @@ conv_fwd_kernel(ConvArgs a) {
                 {
                     const int q = min(g * NTAP + ts + RING - 1, q_last);
 #pragma unroll
-                    for (int ct = 0; ct < C::NCT; ++ct)
-                        wf[(ts + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct) * 1024u);
+                    for (int ct = 0; ct < CTW; ++ct)
+                        wf[(ts + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 1024u);
                     const int tn = (ts + 1 < NTAP) ? ts + 1 : ts;   // last tap: harmless re-read
                     const int toff = tap_off(tn / 9, (tn / 3) % 3, tn % 3);
 #pragma unroll
                     for (int i = 0; i < R; ++i)
                         bb[(ts + 1) & 1][i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
-                    PCC_PIN_MEM_MFMA();
                 }
                 // k-slot quarter j outermost: consecutive MFMAs go to different accumulators (the 40-cycle
                 // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue)
@@ -202,8 +203,16 @@ conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
                     for (int i = 0; i < R; ++i)
 #pragma unroll
-                        for (int ct = 0; ct < C::NCT; ++ct)
+                        for (int ct = 0; ct < CTW; ++ct)
                             acc[i][ct] = mfma16(wf[ts % RING][ct][j], bb[ts & 1][i][j], acc[i][ct]);
+                // issue order of the section: the prefetch loads are spread between groups of MFMAs
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // 1 DS read
+                    if (k < CTW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // 1 weight load
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * CTW, 0);        // 4*NCT MFMA
+                }
+                if (CTW > R) __builtin_amdgcn_sched_group_barrier(0x020, CTW - R, 0);
                 PCC_PIN_MEM_MFMA();
             }
         } else {
@@ -214,8 +223,8 @@ conv_fwd_kernel(ConvArgs a) {
                     const int t = sl * SLAB + ts;
                     const int q = min(g * NTAP + t + RING - 1, q_last);
 #pragma unroll
-                    for (int ct = 0; ct < C::NCT; ++ct)
-                        wf[(ts + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct) * 1024u);
+                    for (int ct = 0; ct < CTW; ++ct)
+                        wf[(ts + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 1024u);
                     PCC_PIN_VMEM();
                     const int toff = tap_off(sl, ts / KS, ts % KS);
                     f32x4 b[R];
@@ -226,7 +235,7 @@ conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
                         for (int i = 0; i < R; ++i)
 #pragma unroll
-                            for (int ct = 0; ct < C::NCT; ++ct)
+                            for (int ct = 0; ct < CTW; ++ct)
                                 acc[i][ct] = mfma16(wf[ts % RING][ct][j], b[i][j], acc[i][ct]);
                 }
             }
@@ -241,7 +250,7 @@ conv_fwd_kernel(ConvArgs a) {
         if (gz < a.OD && gy < a.OH && gx < a.OW) {
             const size_t vox = (((size_t)n * a.OD + gz) * a.OH + gy) * a.OW + gx;
 #pragma unroll
-            for (int ct = 0; ct < C::NCT; ++ct) store_out(a, acc[i][ct], vox, ct * 16 + cq * 4, COUT);
+            for (int ct = 0; ct < CTW; ++ct) store_out(a, acc[i][ct], vox, (ct0 + ct) * 16 + cq * 4, COUT);
         }
     }
 }
@@ -462,13 +471,14 @@ struct Tr2Geo {
     static constexpr int HH = (1 + PL) / 2;           // max(+delta)  (p = 1, kappa = 0 or 1)
 };
 
-template <int CIN, int COUT, int KS, int TX, int TZ, int TY, int TXT, int R>
+template <int CIN, int COUT, int KS, int TX, int TZ, int TY, int TXT, int R, int CTW = COUT / 16>
 struct Tr2Cfg {
     using G = Tr2Geo<KS>;
     static constexpr int NG = CIN / 16, NCT = COUT / 16;
     static constexpr int RY = 16 / TX;
     static constexpr int NYB = TY / RY, NXB = TXT / TX;
-    static constexpr int NW = TZ * (NYB / R) * NXB;
+    static constexpr int NCG = NCT / CTW;
+    static constexpr int NW = TZ * (NYB / R) * NXB * NCG;
     static constexpr int NT = NW * 64;
     static constexpr int LZ = TZ + G::HL + G::HH, LY = TY + G::HL + G::HH, LX = TXT + G::HL + G::HH;
     static constexpr int VS = CIN + 8;
@@ -478,10 +488,10 @@ struct Tr2Cfg {
     static constexpr int ITEMS = (NV * Q + NT - 1) / NT;
 };
 
-template <int CIN, int COUT, int KS, int TX, int TZ, int TY, int TXT, int R>
-__global__ void __launch_bounds__((Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R>::NT))
+template <int CIN, int COUT, int KS, int TX, int TZ, int TY, int TXT, int R, int CTW = COUT / 16>
+__global__ void __launch_bounds__((Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>::NT))
 conv_tr2_kernel(ConvArgs a) {
-    using C = Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R>;
+    using C = Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>;
     using G = Tr2Geo<KS>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -495,6 +505,7 @@ conv_tr2_kernel(ConvArgs a) {
     const int bz0 = tz * TZ, by0 = ty * TY, bx0 = tx * TXT;  // base (input-grid) tile origin
 
     int wv = wave;
+    const int ct0 = (wv % C::NCG) * CTW; wv /= C::NCG;
     const int w_xb = wv % C::NXB; wv /= C::NXB;
     const int w_yg = wv % (C::NYB / R);
     const int w_z = wv / (C::NYB / R);
@@ -536,14 +547,14 @@ conv_tr2_kernel(ConvArgs a) {
     // FULL: the whole (class, tap, g) sequence is unrolled so that a static 3-deep register ring prefetches two
     // units ahead.  For the widest shape (64 -> 64: 3456 MFMAs per wave) that would not fit the instruction
     // cache, so the cin-group loop stays dynamic there and the weights are loaded per (tap, group).
-    constexpr bool FULL = C::NG * C::NCT < 16;
+    constexpr bool FULL = C::NG * CTW < 16 && C::NG * C::NCT < 16;
     constexpr int RING = 3;
-    f32x4 wf[RING][C::NCT];
+    f32x4 wf[RING][CTW];
     if constexpr (FULL) {
 #pragma unroll
         for (int r = 0; r < RING - 1; ++r)
 #pragma unroll
-            for (int ct = 0; ct < C::NCT; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct) * 1024u);
+            for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct0 + ct) * 1024u);
     }
     __syncthreads();
 
@@ -554,11 +565,11 @@ conv_tr2_kernel(ConvArgs a) {
         for (int py = 0; py < 2; ++py)
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
-                f32x4 acc[R][C::NCT];
+                f32x4 acc[R][CTW];
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int ct = 0; ct < C::NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int ct = 0; ct < CTW; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kz = (pz + G::PL) & 1; kz < KS; kz += 2)
 #pragma unroll
@@ -573,8 +584,8 @@ conv_tr2_kernel(ConvArgs a) {
                                     {
                                         const int qn = (seq + RING - 1 < NSEQ) ? seq + RING - 1 : NSEQ - 1;
 #pragma unroll
-                                        for (int ct = 0; ct < C::NCT; ++ct)
-                                            wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(qn * C::NCT + ct) * 1024u);
+                                        for (int ct = 0; ct < CTW; ++ct)
+                                            wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, (unsigned)(qn * C::NCT + ct0 + ct) * 1024u);
                                         PCC_PIN_VMEM();
                                     }
                                     f32x4 b[R];
@@ -586,7 +597,7 @@ conv_tr2_kernel(ConvArgs a) {
 #pragma unroll
                                         for (int i = 0; i < R; ++i)
 #pragma unroll
-                                            for (int ct = 0; ct < C::NCT; ++ct)
+                                            for (int ct = 0; ct < CTW; ++ct)
                                                 acc[i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[i][ct]);
                                 }
                             } else {
@@ -594,10 +605,10 @@ conv_tr2_kernel(ConvArgs a) {
                                 seq += C::NG;
 #pragma unroll 1
                                 for (int g = 0; g < C::NG; ++g) {
-                                    f32x4 w1[C::NCT];
+                                    f32x4 w1[CTW];
 #pragma unroll
-                                    for (int ct = 0; ct < C::NCT; ++ct)
-                                        w1[ct] = buf_load4(rw, wlane, (unsigned)((seq0 + g) * C::NCT + ct) * 1024u);
+                                    for (int ct = 0; ct < CTW; ++ct)
+                                        w1[ct] = buf_load4(rw, wlane, (unsigned)((seq0 + g) * C::NCT + ct0 + ct) * 1024u);
                                     f32x4 b[R];
 #pragma unroll
                                     for (int i = 0; i < R; ++i)
@@ -607,7 +618,7 @@ conv_tr2_kernel(ConvArgs a) {
 #pragma unroll
                                         for (int i = 0; i < R; ++i)
 #pragma unroll
-                                            for (int ct = 0; ct < C::NCT; ++ct)
+                                            for (int ct = 0; ct < CTW; ++ct)
                                                 acc[i][ct] = mfma16(w1[ct][j], b[i][j], acc[i][ct]);
                                 }
                             }
@@ -619,7 +630,7 @@ conv_tr2_kernel(ConvArgs a) {
                     if (gzb < a.D && gyb < a.H && gxb < a.W) {
                         const size_t vox = (((size_t)n * a.OD + 2 * gzb + pz) * a.OH + 2 * gyb + py) * a.OW + 2 * gxb + px;
 #pragma unroll
-                        for (int ct = 0; ct < C::NCT; ++ct) store_out(a, acc[i][ct], vox, ct * 16 + cq * 4, COUT);
+                        for (int ct = 0; ct < CTW; ++ct) store_out(a, acc[i][ct], vox, (ct0 + ct) * 16 + cq * 4, COUT);
                     }
                 }
             }
@@ -1021,16 +1032,27 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 template <int CIN, int COUT, int KS, int S>
 int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
     // tile shapes per row width: (TX, TZ, TY, TXT, R)
-#define PCC_FWD(TX, TZ, TY, TXT, R)                                                                     \
+#define PCC_FWD(TX, TZ, TY, TXT, R) PCC_FWDC(TX, TZ, TY, TXT, R, (COUT / 16))
+#define PCC_FWDC(TX, TZ, TY, TXT, R, CTW)                                                               \
     {                                                                                                   \
-        using C = FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R>;                                         \
+        using C = FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW>;                                    \
         a.ntz = cdiv(a.OD, TZ); a.nty = cdiv(a.OH, TY); a.ntx = cdiv(a.OW, TXT);                        \
-        return launch(conv_fwd_kernel<CIN, COUT, KS, S, TX, TZ, TY, TXT, R>, C::NT, C::LDS_BYTES,       \
+        return launch(conv_fwd_kernel<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,  \
                       a.N * a.ntz * a.nty * a.ntx, a, st);                                              \
     }
     if constexpr (S == 1) {
         if (tx == 16) {
-            if constexpr (COUT >= 64) PCC_FWD(16, 2, 4, 16, 2)
+            if constexpr (COUT >= 64) {
+                // pick the tile whose workgroup count fills the CU slots best (avoids a mostly empty last round)
+                static const int v64 = getenv("PCC_TILE64") ? atoi(getenv("PCC_TILE64")) : -1;
+                const long vox = (long)a.N * a.OD * a.OH * a.OW;
+                const long wg_small = vox / 128, wg_big = vox / 256;          // (2,4,16) vs (2,8,16)
+                const double t_small = (double)((wg_small + 3 * num_cu - 1) / (3 * num_cu)) * 1.0;
+                const double t_big = (double)((wg_big + 2 * num_cu - 1) / (2 * num_cu)) * 2.0;
+                const bool big = v64 >= 0 ? v64 == 1 : t_big <= t_small;
+                if (big) PCC_FWD(16, 2, 8, 16, 4)
+                PCC_FWD(16, 2, 4, 16, 2)
+            }
             else if constexpr (COUT == 16 && CIN == 16 && KS == 3) {
                 static const int variant = getenv("PCC_TILE_VARIANT") ? atoi(getenv("PCC_TILE_VARIANT")) : 11;
 #define PCC_P16(TZ, TY, R, VS, WPC)                                                                     \
@@ -1055,36 +1077,49 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
             }
             else PCC_FWD(16, 2, 8, 16, 4)
         }
-        if (tx == 8) PCC_FWD(8, 2, 8, 8, 2)
-        PCC_FWD(4, 4, 4, 4, 1)
+        // small grids: few voxels per workgroup and the cout tiles split over waves, so that every CU gets work
+        if (tx == 8) {
+            if constexpr (COUT >= 64) PCC_FWDC(8, 2, 4, 8, 1, 1)
+            else PCC_FWD(8, 2, 8, 8, 2)
+        }
+        if constexpr (COUT >= 32) PCC_FWDC(4, 1, 4, 4, 1, 1)
+        else PCC_FWD(4, 4, 4, 4, 1)
     } else if constexpr (KS == 3) {  // stride 2: the staged input tile is 2x larger per dim
         if (tx == 16) PCC_FWD(16, 2, 2, 16, 1)
         if (tx == 8) PCC_FWD(8, 2, 4, 8, 1)
-        PCC_FWD(4, 4, 4, 4, 1)
+        if constexpr (COUT >= 32) PCC_FWDC(4, 1, 4, 4, 1, 1)
+        else PCC_FWD(4, 4, 4, 4, 1)
     } else {
         if (tx == 16) PCC_FWD(16, 1, 2, 16, 1)
         if (tx == 8) PCC_FWD(8, 1, 4, 8, 1)
         PCC_FWD(4, 4, 4, 4, 1)
     }
 #undef PCC_FWD
+#undef PCC_FWDC
 }
 
 template <int CIN, int COUT, int KS>
 int launch_tr2(int tx, ConvArgs a, hipStream_t st) {
-#define PCC_TR2(TX, TZ, TY, TXT, R)                                                                     \
+#define PCC_TR2(TX, TZ, TY, TXT, R) PCC_TR2C(TX, TZ, TY, TXT, R, (COUT / 16))
+#define PCC_TR2C(TX, TZ, TY, TXT, R, CTW)                                                               \
     {                                                                                                   \
-        using C = Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R>;                                            \
+        using C = Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>;                                       \
         a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
-        return launch(conv_tr2_kernel<CIN, COUT, KS, TX, TZ, TY, TXT, R>, C::NT, C::LDS_BYTES,          \
+        return launch(conv_tr2_kernel<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,     \
                       a.N * a.ntz * a.nty * a.ntx, a, st);                                              \
     }
     if (tx == 16) {
         if constexpr (CIN >= 64) PCC_TR2(16, 2, 4, 16, 2)
         else PCC_TR2(16, 2, 8, 16, 4)
     }
-    if (tx == 8) PCC_TR2(8, 2, 8, 8, 2)
-    PCC_TR2(4, 4, 4, 4, 1)
+    if (tx == 8) {
+        if constexpr (COUT >= 64 && KS == 3) PCC_TR2C(8, 2, 4, 8, 1, 1)
+        else PCC_TR2(8, 2, 8, 8, 2)
+    }
+    if constexpr (COUT >= 32 && KS == 3) PCC_TR2C(4, 1, 4, 4, 1, 1)
+    else PCC_TR2(4, 4, 4, 4, 1)
 #undef PCC_TR2
+#undef PCC_TR2C
 }
 
 }  // namespace
