@@ -22,7 +22,14 @@
 
 #include "common.h"
 
-namespace {
+// Compiled several times with -DPCC_PART=k (see Makefile): part 0 holds the dispatcher, the weight packer and the
+// first/last-layer kernels; parts 1.. hold the explicit instantiations of launch_fwd<> / launch_tr2<> so that the
+// heavily unrolled kernels build in parallel.
+#ifndef PCC_PART
+#define PCC_PART 0
+#endif
+
+namespace pccmfma {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -145,41 +152,57 @@ conv_fwd_kernel(ConvArgs a) {
     constexpr int SLAB = (KS == 3) ? NTAP : KS * KS;   // taps unrolled per dynamic iteration
     static_assert(SLAB % RING == 0, "ring phase must be static");
     const int q_last = C::NG * NTAP - 1;
+    auto tap_off = [](int kz, int ky, int kx) { return ((kz * C::LY + ky) * C::LX + kx) * C::VS; };
 
-#pragma unroll 1
-    for (int g = 0; g < C::NG; ++g) {
-        // ---- stage 16 channels of the haloed input tile (hardware zero fill = SAME padding)
-        f32x4 stg[C::ITEMS];
+    // per-thread staging items: byte offset of channel group 0 inside the image, or kOOB (reads as zeros)
+    unsigned soff[C::ITEMS];
 #pragma unroll
-        for (int it = 0; it < C::ITEMS; ++it) {
-            const int item = it * C::NT + tid;
-            const int u = item >> 2, q = item & 3;
-            const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
-            const int ly = rem / C::LX, lx = rem - ly * C::LX;
-            const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
-            const bool ok = (item < C::NV * 4) && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const unsigned off = (unsigned)(((gz * a.H + gy) * a.W + gx) * CIN + g * 16 + q * 4) * 4u;
-            stg[it] = buf_load4(rin, ok ? off : kOOB, 0);
-        }
-        f32x4 wf[RING][CTW];
-#pragma unroll
-        for (int r = 0; r < RING - 1; ++r) {
-            const int q = min(g * NTAP + r, q_last);
-#pragma unroll
-            for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 1024u);
-        }
-        if (g > 0) __syncthreads();  // all waves finished reading the previous group
+    for (int it = 0; it < C::ITEMS; ++it) {
+        const int item = it * C::NT + tid;
+        const int u = item >> 2, q = item & 3;
+        const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
+        const int ly = rem / C::LX, lx = rem - ly * C::LX;
+        const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
+        const bool ok = (item < C::NV * 4) & (gz >= 0) & (gz < a.D) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+        soff[it] = ok ? (unsigned)(((gz * a.H + gy) * a.W + gx) * CIN + q * 4) * 4u : kOOB;
+    }
+    auto commit = [&](const f32x4 (&stg)[C::ITEMS]) {
 #pragma unroll
         for (int it = 0; it < C::ITEMS; ++it) {
             const int item = it * C::NT + tid;
             if (item < C::NV * 4) *reinterpret_cast<f32x4*>(lds + (item >> 2) * C::VS + (item & 3) * 4) = stg[it];
         }
+    };
+
+    if constexpr (KS == 3) {
+        // ---- k3: software pipeline over the channel groups of the tile.  While group g is contracted (27 taps),
+        //      the staging loads of group g+1 (one item per tap) and, in the last group, the residual rows are in
+        //      flight; the weight ring runs continuously across groups.
+        constexpr int NRES = R * CTW;                       // residual float4 per lane
+        constexpr int RES0 = (27 - NRES) > 0 ? 27 - NRES : 0;
+        static_assert(C::ITEMS <= 27 && NRES <= 27, "prefetch is spread over the tap sections");
+        f32x4 stg[C::ITEMS];
+#pragma unroll
+        for (int it = 0; it < C::ITEMS; ++it) stg[it] = buf_load4(rin, soff[it], 0);
+        f32x4 wf[RING][CTW];
+#pragma unroll
+        for (int r = 0; r < RING - 1; ++r)
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(min(r, q_last) * C::NCT + ct0 + ct) * 1024u);
+        commit(stg);
         __syncthreads();
 
-        auto tap_off = [](int kz, int ky, int kx) { return ((kz * C::LY + ky) * C::LX + kx) * C::VS; };
-        if constexpr (KS == 3) {
-            // B operands (LDS rows) are double-buffered in registers one tap ahead of the MFMAs that use them;
-            // the two sched_barriers keep [prefetch loads | MFMAs] in the written order.
+        // residual rows of this wave (prefetched during the last group)
+        const int gzo = oz0 + w_z;
+        const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + (size_t)n * a.OD * a.OH * a.OW * COUT : a.in,
+                                                      has_res ? (unsigned)a.OD * a.OH * a.OW * COUT * 4u : 0u);
+        f32x4 resv[R][CTW];
+
+#pragma unroll 1
+        for (int g = 0; g < C::NG; ++g) {
+            const unsigned gnext = (unsigned)min(g + 1, C::NG - 1) * 64u;     // last group: harmless re-read
+            const bool last = g == C::NG - 1;
             f32x4 bb[2][R];
 #pragma unroll
             for (int i = 0; i < R; ++i) bb[0][i] = *reinterpret_cast<const f32x4*>(lbase + i * ROW_OFF);
@@ -195,6 +218,14 @@ conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
                     for (int i = 0; i < R; ++i)
                         bb[(ts + 1) & 1][i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
+                    if (ts < C::ITEMS) stg[ts] = buf_load4(rin, soff[ts], gnext);
+                    if (ts >= RES0 && ts < RES0 + NRES) {
+                        const int i = (ts - RES0) / CTW, ct = (ts - RES0) % CTW;
+                        const int gy = oy0 + ly0 + i * C::RY, gx = ox0 + lx0;
+                        const bool ok = last & has_res & (gzo < a.OD) & (gy < a.OH) & (gx < a.OW);
+                        const unsigned off = (unsigned)(((gzo * a.OH + gy) * a.OW + gx) * COUT + (ct0 + ct) * 16 + cq * 4) * 4u;
+                        resv[i][ct] = buf_load4(rres, ok ? off : kOOB, 0);
+                    }
                 }
                 // k-slot quarter j outermost: consecutive MFMAs go to different accumulators (the 40-cycle
                 // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue)
@@ -205,17 +236,51 @@ conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
                         for (int ct = 0; ct < CTW; ++ct)
                             acc[i][ct] = mfma16(wf[ts % RING][ct][j], bb[ts & 1][i][j], acc[i][ct]);
-                // issue order of the section: the prefetch loads are spread between groups of MFMAs
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // 1 DS read
-                    if (k < CTW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // 1 weight load
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * CTW, 0);        // 4*NCT MFMA
-                }
-                if (CTW > R) __builtin_amdgcn_sched_group_barrier(0x020, CTW - R, 0);
                 PCC_PIN_MEM_MFMA();
             }
-        } else {
+            if (!last) {
+                __syncthreads();   // every wave finished reading group g
+                commit(stg);
+                __syncthreads();
+            }
+        }
+        // ---- epilogue (residual already in registers)
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int gy = oy0 + ly0 + i * C::RY, gx = ox0 + lx0;
+            if (gzo < a.OD && gy < a.OH && gx < a.OW) {
+                const size_t vox = (((size_t)n * a.OD + gzo) * a.OH + gy) * a.OW + gx;
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) {
+                    f32x4 o = acc[i][ct];
+                    const int c0 = (ct0 + ct) * 16 + cq * 4;
+                    if (a.flags & PCC_CONV_BIAS) o += *reinterpret_cast<const f32x4*>(a.bias + c0);
+                    if (a.flags & PCC_CONV_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    if (has_res) o += resv[i][ct];
+                    if (a.flags & PCC_CONV_CLIP01) {
+                        o.x = fminf(fmaxf(o.x, 0.f), 1.f); o.y = fminf(fmaxf(o.y, 0.f), 1.f);
+                        o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
+                    }
+                    *reinterpret_cast<f32x4*>(a.out + vox * a.ocs + a.oco + c0) = o;
+                }
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int g = 0; g < C::NG; ++g) {
+            f32x4 stg[C::ITEMS];
+#pragma unroll
+            for (int it = 0; it < C::ITEMS; ++it) stg[it] = buf_load4(rin, soff[it], (unsigned)g * 64u);
+            f32x4 wf[RING][CTW];
+#pragma unroll
+            for (int r = 0; r < RING - 1; ++r) {
+                const int q = min(g * NTAP + r, q_last);
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 1024u);
+            }
+            if (g > 0) __syncthreads();  // all waves finished reading the previous group
+            commit(stg);
+            __syncthreads();
 #pragma unroll 1
             for (int sl = 0; sl < NTAP / SLAB; ++sl) {
 #pragma unroll
@@ -240,17 +305,16 @@ conv_fwd_kernel(ConvArgs a) {
                 }
             }
         }
-    }
-
-    // ---- epilogue
-    const int gz = oz0 + w_z;
+        // ---- epilogue
+        const int gz = oz0 + w_z;
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int gy = oy0 + ly0 + i * C::RY, gx = ox0 + lx0;
-        if (gz < a.OD && gy < a.OH && gx < a.OW) {
-            const size_t vox = (((size_t)n * a.OD + gz) * a.OH + gy) * a.OW + gx;
+        for (int i = 0; i < R; ++i) {
+            const int gy = oy0 + ly0 + i * C::RY, gx = ox0 + lx0;
+            if (gz < a.OD && gy < a.OH && gx < a.OW) {
+                const size_t vox = (((size_t)n * a.OD + gz) * a.OH + gy) * a.OW + gx;
 #pragma unroll
-            for (int ct = 0; ct < CTW; ++ct) store_out(a, acc[i][ct], vox, (ct0 + ct) * 16 + cq * 4, COUT);
+                for (int ct = 0; ct < CTW; ++ct) store_out(a, acc[i][ct], vox, (ct0 + ct) * 16 + cq * 4, COUT);
+            }
         }
     }
 }
@@ -837,6 +901,7 @@ __global__ void __launch_bounds__((Cout1Cfg<CIN, KS, S, TZ, TY, TXT>::NT)) conv_
     }
 }
 
+#if PCC_PART == 0
 // =====================================================================================================
 // Conv3DTranspose 16 -> 1, k3, stride 1 (last layer of the V2 synthesis transforms) on the matrix cores.
 //   A GEMV-shaped layer has no N dimension for an implicit GEMM, so the contraction is split:
@@ -961,6 +1026,8 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
     finish(accC, a.D - 1);
 }
 
+#endif  // PCC_PART == 0 (non-template kernel)
+
 // =====================================================================================================
 // host side: kernel selection, launch, weight packing
 // =====================================================================================================
@@ -977,7 +1044,7 @@ inline int base_w(const pcc_conv_desc* d) {  // x extent of the grid the rows li
     return pcc_same_out(d->W, d->stride);
 }
 
-Plan make_plan(const pcc_conv_desc* d) {
+static Plan make_plan(const pcc_conv_desc* d) {
     Plan p;
     if ((double)d->D * d->H * d->W * d->Cin * 4.0 >= 2147483648.0) return p;
     const bool out_vec_ok = d->out_cstride == 0 || (d->out_cstride % 4 == 0 && d->out_coffset % 4 == 0);
@@ -1044,36 +1111,21 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
         if (tx == 16) {
             if constexpr (COUT >= 64) {
                 // pick the tile whose workgroup count fills the CU slots best (avoids a mostly empty last round)
-                static const int v64 = getenv("PCC_TILE64") ? atoi(getenv("PCC_TILE64")) : -1;
                 const long vox = (long)a.N * a.OD * a.OH * a.OW;
                 const long wg_small = vox / 128, wg_big = vox / 256;          // (2,4,16) vs (2,8,16)
                 const double t_small = (double)((wg_small + 3 * num_cu - 1) / (3 * num_cu)) * 1.0;
                 const double t_big = (double)((wg_big + 2 * num_cu - 1) / (2 * num_cu)) * 2.0;
-                const bool big = v64 >= 0 ? v64 == 1 : t_big <= t_small;
+                const bool big = t_big <= t_small;
                 if (big) PCC_FWD(16, 2, 8, 16, 4)
                 PCC_FWD(16, 2, 4, 16, 2)
             }
             else if constexpr (COUT == 16 && CIN == 16 && KS == 3) {
-                static const int variant = getenv("PCC_TILE_VARIANT") ? atoi(getenv("PCC_TILE_VARIANT")) : 11;
-#define PCC_P16(TZ, TY, R, VS, WPC)                                                                     \
-    {                                                                                                   \
-        using P = P16Cfg<TZ, TY, R, VS>;                                                                \
-        a.ntz = cdiv(a.OD, TZ); a.nty = cdiv(a.OH, TY); a.ntx = cdiv(a.OW, 16);                         \
-        const int ntiles = a.N * a.ntz * a.nty * a.ntx;                                                 \
-        const int grid = ntiles < num_cu * WPC ? ntiles : num_cu * WPC;                                 \
-        return launch(conv16_pers_kernel<TZ, TY, R, VS, WPC>, P::NT, P::LDS_BYTES, grid, a, st, ntiles); \
-    }
-                if (variant == 10) PCC_P16(2, 8, 4, 24, 1)
-                if (variant == 11) PCC_P16(2, 4, 2, 20, 2)
-                if (variant == 12) PCC_P16(2, 8, 4, 20, 1)
-                if (variant == 13) PCC_P16(2, 4, 2, 24, 1)
-#undef PCC_P16
-                if (variant == 1) PCC_FWD(16, 1, 8, 16, 2)
-                if (variant == 2) PCC_FWD(16, 2, 4, 16, 2)
-                if (variant == 3) PCC_FWD(16, 4, 8, 16, 4)
-                if (variant == 4) PCC_FWD(16, 2, 8, 16, 2)
-                if (variant == 5) PCC_FWD(16, 1, 16, 16, 4)
-                PCC_FWD(16, 2, 8, 16, 4)
+                // persistent kernel, 2 workgroups per CU (tile 2x4x16, 80-byte LDS voxel stride)
+                using P = P16Cfg<2, 4, 2, 20>;
+                a.ntz = cdiv(a.OD, 2); a.nty = cdiv(a.OH, 4); a.ntx = cdiv(a.OW, 16);
+                const int ntiles = a.N * a.ntz * a.nty * a.ntx;
+                const int grid = ntiles < num_cu * 2 ? ntiles : num_cu * 2;
+                return launch(conv16_pers_kernel<2, 4, 2, 20, 2>, P::NT, P::LDS_BYTES, grid, a, st, ntiles);
             }
             else PCC_FWD(16, 2, 8, 16, 4)
         }
@@ -1122,7 +1174,43 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st) {
 #undef PCC_TR2C
 }
 
-}  // namespace
+
+// ---- explicit instantiation lists: (CIN, COUT, KS, S) for launch_fwd, (CIN, COUT, KS) for launch_tr2 ------------
+#define PCC_FWD_P1(X) X(16, 16, 3, 1) X(16, 32, 3, 2)
+#define PCC_FWD_P2(X) X(32, 32, 3, 1) X(32, 32, 3, 2)
+#define PCC_FWD_P3(X) X(64, 64, 3, 1) X(64, 64, 3, 2) X(32, 64, 3, 2)
+#define PCC_FWD_P4(X) X(32, 32, 5, 2)
+#define PCC_TR2_P4(X) X(32, 32, 5)
+#define PCC_TR2_P5(X) X(64, 64, 3) X(64, 32, 3)
+#define PCC_TR2_P6(X) X(32, 16, 3) X(32, 32, 3)
+#define PCC_FWD_ALL(X) PCC_FWD_P1(X) PCC_FWD_P2(X) PCC_FWD_P3(X) PCC_FWD_P4(X)
+#define PCC_TR2_ALL(X) PCC_TR2_P4(X) PCC_TR2_P5(X) PCC_TR2_P6(X)
+#define PCC_INST_FWD(CI, CO, K, S) template int launch_fwd<CI, CO, K, S>(int, ConvArgs, hipStream_t, int);
+#define PCC_INST_TR2(CI, CO, K) template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t);
+#define PCC_EXT_FWD(CI, CO, K, S) extern template int launch_fwd<CI, CO, K, S>(int, ConvArgs, hipStream_t, int);
+#define PCC_EXT_TR2(CI, CO, K) extern template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t);
+#if PCC_PART == 0
+PCC_FWD_ALL(PCC_EXT_FWD)
+PCC_TR2_ALL(PCC_EXT_TR2)
+#elif PCC_PART == 1
+PCC_FWD_P1(PCC_INST_FWD)
+#elif PCC_PART == 2
+PCC_FWD_P2(PCC_INST_FWD)
+#elif PCC_PART == 3
+PCC_FWD_P3(PCC_INST_FWD)
+#elif PCC_PART == 4
+PCC_FWD_P4(PCC_INST_FWD)
+PCC_TR2_P4(PCC_INST_TR2)
+#elif PCC_PART == 5
+PCC_TR2_P5(PCC_INST_TR2)
+#elif PCC_PART == 6
+PCC_TR2_P6(PCC_INST_TR2)
+#endif
+
+}  // namespace pccmfma
+
+#if PCC_PART == 0
+using namespace pccmfma;
 
 PCC_API int pcc_conv_mfma_supported(const pcc_conv_desc* d) {
     if (!d) return 0;
@@ -1255,3 +1343,5 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
     pcc_set_error("pcc_conv3d_mfma: no instantiation for Cin=%d Cout=%d k=%d s=%d transposed=%d", ci, co, k, s, d->transposed);
     return PCC_ERR_ARG;
 }
+
+#endif  // PCC_PART == 0
