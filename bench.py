@@ -115,7 +115,9 @@ def main():
     torch.cuda.set_device(device)
     ctx = ops.get_context(device)
 
-    model = ModelConfigType['c3p'].build(batch_size=args.chunk)
+    # host range-coder threads: share the node's cores between the ranks
+    coder_threads = max(8, (os.cpu_count() or 8) // max(world, 1))
+    model = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads)
     model.compress([1, 1, RES, RES, RES])
     w = synthetic_weights(model)
     model.set_weights(w)
@@ -178,7 +180,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'c3p, lambda-independent graph, batch=32 synthetic 64^3 occupancy grids per GPU, '
                                    'fixed threshold idx 128, encode+decode (BASELINE.json configs[1])',
-                       'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'sharding': f'blocks x{world}',
+                       'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'coder_threads_per_rank': coder_threads, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
                        'bytes_per_block': n_bytes / n_blocks, 'decoded_points_per_block': n_pts / n_blocks,
                        'conv_tflops_whole_step': value * FLOPS_PER_BLOCK / 1e12,

@@ -1121,11 +1121,18 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
             }
             else if constexpr (COUT == 16 && CIN == 16 && KS == 3) {
                 // persistent kernel, 2 workgroups per CU (tile 2x4x16, 80-byte LDS voxel stride)
-                using P = P16Cfg<2, 4, 2, 20>;
-                a.ntz = cdiv(a.OD, 2); a.nty = cdiv(a.OH, 4); a.ntx = cdiv(a.OW, 16);
-                const int ntiles = a.N * a.ntz * a.nty * a.ntx;
-                const int grid = ntiles < num_cu * 2 ? ntiles : num_cu * 2;
-                return launch(conv16_pers_kernel<2, 4, 2, 20, 2>, P::NT, P::LDS_BYTES, grid, a, st, ntiles);
+#define PCC_P16(TZ, TY, R, VS, WPC)                                                                     \
+    {                                                                                                   \
+        using P = P16Cfg<TZ, TY, R, VS>;                                                                \
+        a.ntz = cdiv(a.OD, TZ); a.nty = cdiv(a.OH, TY); a.ntx = cdiv(a.OW, 16);                         \
+        const int ntiles = a.N * a.ntz * a.nty * a.ntx;                                                 \
+        const int grid = ntiles < num_cu * WPC ? ntiles : num_cu * WPC;                                 \
+        return launch(conv16_pers_kernel<TZ, TY, R, VS, WPC>, P::NT, P::LDS_BYTES, grid, a, st, ntiles); \
+    }
+                static const int pv = getenv("PCC_P16") ? atoi(getenv("PCC_P16")) : 0;
+                if (pv == 1) PCC_P16(2, 8, 2, 20, 1)     // one 8-wave workgroup per CU (same speed, fewer halo re-reads)
+                PCC_P16(2, 4, 2, 20, 2)
+#undef PCC_P16
             }
             else PCC_FWD(16, 2, 8, 16, 4)
         }
