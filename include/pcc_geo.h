@@ -124,6 +124,24 @@ size_t pcc_threshold_scratch_ints(int32_t B, int32_t D, int32_t H, int32_t W);
 int pcc_voxelize(pcc_ctx* ctx, const int32_t* pts, const int32_t* block_of, int64_t npts,
                  int32_t B, int32_t D, int32_t H, int32_t W, float* dense, void* stream);
 
+/* ---- adaptive threshold search statistics (src/model_opt.py:21-77, src/utils/pc_metric.py:76-138) ------------
+ * Exact D1 sums for EVERY threshold of EVERY block in one call (the reference builds up to 255 KD-trees per block).
+ * With level k(v) = #{t : x_hat[v] > thr[t]} the decoded set at threshold t is B_t = {v : k(v) > t}.  Outputs
+ * (device, (B,256) uint64 unless noted, zero-filled by the call):
+ *   s_ab[b][t]  = sum over the original points a of block b of min_{v in B_t} |a - v|^2        (d1_sum_AB)
+ *   hsum[b][k]  = sum over voxels of level k of min_a |v - a|^2;  d1_sum_BA(t) = sum_{k>t} hsum[b][k]
+ *   hcnt[b][k]  = number of voxels of level k;                    |B_t|        = sum_{k>t} hcnt[b][k]
+ *   tcount[b]   (int32, (B,)) = number of thresholds whose decoded set is non-empty.
+ * All sums are integers, so the host reproduces the reference's float64 metrics bit for bit.
+ * pts: (npts,3) int32 block-local coordinates, block_of: (npts,) int32; thr: nthr <= 256 increasing float32
+ * thresholds (device).  clip != 0 applies np.clip(x_hat,0,1) first (the encoder does, model_types.py:202).
+ * Blocks up to 128^3.  `workspace`: pcc_d1_search_workspace_bytes(B,D,H,W) bytes of device memory.             */
+size_t pcc_d1_search_workspace_bytes(int32_t B, int32_t D, int32_t H, int32_t W);
+int pcc_d1_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, int32_t D, int32_t H, int32_t W,
+                           const float* thr, int32_t nthr, int32_t clip, const int32_t* pts,
+                           const int32_t* block_of, int64_t npts, void* workspace, uint64_t* s_ab,
+                           uint64_t* hsum, uint64_t* hcnt, int32_t* tcount, void* stream);
+
 /* ---- focal loss (src/utils/focal_loss.py:5-12) ------------------------------------------
  * Deterministic two-stage reduction (wavefront DPP/shuffle tree, fixed block order); result is a
  * single float32 written to out[0] (device).  `scratch` must hold pcc_focal_scratch_floats().   */

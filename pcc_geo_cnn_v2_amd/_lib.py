@@ -20,6 +20,7 @@ EXPORTS = [
     'pcc_conv3d', 'pcc_quantize', 'pcc_dequantize', 'pcc_scale_to_index', 'pcc_threshold_compact',
     'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
     'pcc_range_encode_batch', 'pcc_range_decode_batch', 'pcc_pmf_to_quantized_cdf',
+    'pcc_d1_search_workspace_bytes', 'pcc_d1_threshold_stats',
 ]
 
 
@@ -78,6 +79,9 @@ def lib():
     L.pcc_range_encode_batch.argtypes = [C.POINTER(CdfTable), i32, vp, vp, i32, vp, vp, vp, vp, i32]
     L.pcc_range_decode_batch.argtypes = [C.POINTER(CdfTable), i32, vp, vp, vp, i32, vp, vp, i32]
     L.pcc_pmf_to_quantized_cdf.argtypes = [vp, i32, i32, vp]
+    L.pcc_d1_search_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.pcc_d1_search_workspace_bytes.restype = sz
+    L.pcc_d1_threshold_stats.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ('pcc_abi_version',):

@@ -72,3 +72,70 @@ def compute_optimal_thresholds(block, x_hat, thresholds, resolution, normals=Non
             best_thresholds.append(final_idx)
     assert len(ret_opt_metrics) == len(best_thresholds)
     return ret_opt_metrics, best_thresholds
+
+
+def select_thresholds_from_stats(block, s_ab, s_ba, n_b, tcount, n_thresholds, resolution, opt_metrics, max_deltas):
+    """The decision logic of compute_optimal_thresholds (model_opt.py:33-73) applied to exact per-threshold D1 sums
+    (integers) of one block, as produced by ops.d1_threshold_stats.  Only d1_* metrics (no normals)."""
+    ret_opt_metrics = [f'{opt_metric}_{max_delta}' for max_delta in max_deltas for opt_metric in opt_metrics]
+    max_threshold_idx = n_thresholds - 1
+    T = int(tcount)                                   # thresholds 0..T-1 have a non-empty decoded set (pa_list)
+    if T == 0:
+        return ret_opt_metrics, [max_threshold_idx] * len(opt_metrics)
+    nA = len(block)
+    sab, sba, nb = s_ab[:T].astype(np.float64), s_ba[:T].astype(np.float64), n_b[:T].astype(np.float64)
+    met = {'d1_sum_AB': sab, 'd1_sum_BA': sba, 'd1_sum_max': np.maximum(sab, sba), 'd1_sum_mean': (sab + sba) / 2,
+           'd1_mse_AB': sab / nA, 'd1_mse_BA': sba / nb}
+    met['d1_mse'] = np.maximum(met['d1_mse_AB'], met['d1_mse_BA'])
+    # single mean point (failure guard, :59-68)
+    pts = np.asarray(block)[:, :3].astype(np.float64)
+    mp = np.round(np.mean(pts, axis=0))
+    d = np.sum((pts - mp) ** 2, axis=1)
+    m_ab, m_ba = float(np.sum(d)), float(np.min(d))
+    mean_met = {'d1_sum_AB': m_ab, 'd1_sum_BA': m_ba, 'd1_sum_max': max(m_ab, m_ba), 'd1_sum_mean': (m_ab + m_ba) / 2,
+                'd1_mse_AB': m_ab / nA, 'd1_mse_BA': m_ba / 1.0}
+    mean_met['d1_mse'] = max(mean_met['d1_mse_AB'], mean_met['d1_mse_BA'])
+    best_thresholds = []
+    for max_delta in max_deltas:
+        idxs = np.arange(T)
+        if max_delta is not None:
+            ratio = nb / nA
+            elig = idxs[((1 / max_delta) < ratio) & (ratio < max_delta)]
+            if len(elig) > 0:
+                idxs = elig
+        for opt_metric in opt_metrics:
+            vals = met[opt_metric][idxs]
+            j = int(np.argmin(vals))
+            if vals[j] > mean_met[opt_metric]:
+                best_thresholds.append(max_threshold_idx)
+            else:
+                best_thresholds.append(int(idxs[j]))
+    return ret_opt_metrics, best_thresholds
+
+
+def gpu_search_supported(opt_metrics, normals, dhw):
+    return normals is None and all(m.startswith('d1_') for m in opt_metrics) and max(dhw) <= 128
+
+
+def compute_optimal_thresholds_gpu(ctx, blocks, x_hat, thresholds, resolution, opt_metrics=('d1_mse',),
+                                   max_deltas=(np.inf,)):
+    """compute_optimal_thresholds for a batch of blocks with all KD-tree work replaced by exact distance transforms on
+    the GPU.  blocks: list of (n_i, >=3) arrays; x_hat: (B,D,H,W) float32 device tensor (clipped inside, like
+    model_types.py:202).  Returns (ret_opt_metrics, [best thresholds per block])."""
+    import torch
+    from . import ops
+    from .utils.pc_metric import validate_opt_metrics
+    validate_opt_metrics(opt_metrics, with_normals=False)
+    B = len(blocks)
+    # C-contiguous (n,3): np.argwhere-style inputs are transposed views and would otherwise stay Fortran-ordered
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(b)[:, :3] for b in blocks]).astype(np.uint32).astype(np.int32))
+    bof = np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(blocks)])
+    thr = torch.from_numpy(np.asarray(thresholds).astype(np.float32)).to(ctx.device)
+    s_ab, s_ba, n_b, tcount = ops.d1_threshold_stats(ctx, x_hat, thr, torch.from_numpy(pts).to(ctx.device),
+                                                     torch.from_numpy(bof).to(ctx.device), clip=True)
+    names, best = None, []
+    for i in range(B):
+        names, bt = select_thresholds_from_stats(blocks[i], s_ab[i], s_ba[i], n_b[i], tcount[i], len(thresholds),
+                                                 resolution, list(opt_metrics), list(max_deltas))
+        best.append(bt)
+    return names, best

@@ -25,7 +25,7 @@ from . import _lib as L
 from . import model_transforms as MT
 from . import ops
 from .entropy_models import EntropyBottleneck, GaussianConditional, scale_table
-from .model_opt import compute_optimal_thresholds
+from .model_opt import compute_optimal_thresholds, compute_optimal_thresholds_gpu, gpu_search_supported
 from .model_transforms import TransformType
 from .utils.octree_coding import departition_octree
 from .utils.pc_metric import compute_metrics
@@ -155,7 +155,7 @@ class CompressionModel:
     def _voxelize(self, ctx, blocks, dhw):
         D, H, W = dhw
         B = len(blocks)
-        pts = np.concatenate([np.asarray(b)[:, :3] for b in blocks]).astype(np.uint32).astype(np.int32)
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(b)[:, :3] for b in blocks]).astype(np.uint32).astype(np.int32))
         bof = np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(blocks)])
         return ops.voxelize(ctx, torch.from_numpy(pts).to(ctx.device), torch.from_numpy(bof).to(ctx.device), B, D, H, W)
 
@@ -251,6 +251,19 @@ class CompressionModel:
                 for j in range(len(chunk)):
                     threshold_list.append([half] * n_m)
                     x_hat_list.append([pts[j]] * n_m)
+            elif gpu_search_supported(opt_metrics, get_normals_if(chunk[0], with_normals), dhw):
+                # adaptive search on the GPU: exact distance transforms instead of <= 255 KD-trees per block
+                opt_metrics_ret, best_all = compute_optimal_thresholds_gpu(ctx, chunk, x_hat, self.thresholds, resolution,
+                                                                          opt_metrics, max_deltas)
+                n_m = len(best_all[0])
+                per_metric = []
+                for m in range(n_m):
+                    xyz, counts = self._extract_points(ctx, x_hat, [bt[m] for bt in best_all], clip=True)
+                    per_metric.append(self._gather_points(xyz, counts))
+                strings = enc['finish']()
+                for j in range(len(chunk)):
+                    threshold_list.append(list(best_all[j]))
+                    x_hat_list.append([per_metric[m][j] for m in range(n_m)])
             else:
                 strings = enc['finish']()
                 xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)

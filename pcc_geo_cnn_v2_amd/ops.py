@@ -207,6 +207,28 @@ def focal_loss(ctx, y_true, y_pred, gamma=2.0, alpha=0.9):
     return out[0]
 
 
+def d1_threshold_stats(ctx, x_hat, thr, pts, block_of, clip=True):
+    """Exact D1 sums for every threshold of every block (see include/pcc_geo.h).  x_hat (B,D,H,W) float32,
+    thr (T<=256,) float32, pts (n,3) int32 grouped by block, block_of (n,) int32 -- all on the device.
+    Returns int64 numpy arrays s_ab (B,256), s_ba (B,256), n_b (B,256) indexed by threshold, and tcount (B,)."""
+    assert x_hat.dtype == torch.float32 and x_hat.is_contiguous() and x_hat.dim() == 4
+    assert pts.dtype == torch.int32 and pts.is_contiguous() and block_of.dtype == torch.int32 and block_of.is_contiguous()
+    assert thr.dtype == torch.float32 and thr.is_contiguous()
+    B, D, H, W = x_hat.shape
+    ws = torch.empty((L.lib().pcc_d1_search_workspace_bytes(B, D, H, W),), dtype=torch.uint8, device=x_hat.device)
+    s_ab = torch.empty((B, 256), dtype=torch.int64, device=x_hat.device)
+    hsum, hcnt = torch.empty_like(s_ab), torch.empty_like(s_ab)
+    tcount = torch.empty((B,), dtype=torch.int32, device=x_hat.device)
+    L.check(L.lib().pcc_d1_threshold_stats(ctx.handle, _ptr(x_hat), B, D, H, W, _ptr(thr), thr.numel(), int(clip),
+                                           _ptr(pts), _ptr(block_of), pts.shape[0], _ptr(ws), _ptr(s_ab), _ptr(hsum),
+                                           _ptr(hcnt), _ptr(tcount), ctx.stream), 'pcc_d1_threshold_stats')
+    hs, hc = hsum.cpu().numpy(), hcnt.cpu().numpy()
+    # suffix sums over levels k > t
+    s_ba = np.concatenate([np.cumsum(hs[:, ::-1], 1)[:, ::-1][:, 1:], np.zeros((B, 1), np.int64)], 1)
+    n_b = np.concatenate([np.cumsum(hc[:, ::-1], 1)[:, ::-1][:, 1:], np.zeros((B, 1), np.int64)], 1)
+    return s_ab.cpu().numpy(), s_ba, n_b, tcount.cpu().numpy()
+
+
 # ---------------------------------------------------------------------------------------------
 # host range coder
 # ---------------------------------------------------------------------------------------------

@@ -140,3 +140,36 @@ def test_adaptive_threshold_path(ctx):
     assert len(data_list[0]) == len(blocks)
     for strings, t in data_list[0]:
         assert 0 <= t <= 255 and len(strings) == 2
+
+
+def test_blocks_128_cubed_roundtrip_and_layer_parity(ctx, oracle):
+    """BASELINE.json configs[4] shape (c3p graph, 128^3 blocks) on the fp32 path: the nets are fully convolutional
+    (x_shape // 8, // 16 at model_types.py:305,403).  Size-independent checks: enc -> dec bit-identical, decoded point
+    list == np.argwhere; plus oracle parity of the first analysis layer and the heaviest synthesis layer on a slab."""
+    res = 128
+    rng = np.random.default_rng(5)
+    enc = ModelConfigType['c3p'].build(batch_size=2)
+    enc.compress([1, 1, res, res, res])
+    enc.set_weights(scaled_weights(enc, 2.2))
+    x = (torch.rand((2, res, res, res), generator=torch.Generator().manual_seed(3)) < 0.02).float().to(ctx.device)
+    e = enc._encode_batch(ctx, x, debug=True)
+    strings = e['finish']()
+    dec = ModelConfigType['c3p'].build(batch_size=1)
+    dec.decompress()
+    dec.set_weights({k: v for k, v in enc.get_weights().items() if not k.startswith(('analysis/', 'hyper_analysis/'))})
+    blocks, dbg = dec.decompress_blocks(ctx, [(s, 128) for s in strings], [res] * 3, debug=True)
+    for b in range(2):
+        assert np.array_equal(e['debug'][b]['x_hat'], dbg[b]['x_hat'])
+        xh = dbg[b]['x_hat'][0, ..., 0]
+        assert xh.shape == (res, res, res)
+        assert np.array_equal(np.argwhere(xh > np.float32(np.linspace(0, 1, 256)[128])).astype(np.float32), blocks[b])
+    # oracle parity of single layers at this width (W = 128 / 64 rows of the MFMA tiling)
+    first = enc.analysis_transform.conv_layers()[0].layer
+    got = ops.conv3d(ctx, x[:1, :16].unsqueeze(-1).contiguous(), first).cpu().numpy()
+    ref = oracle.conv3d(x[:1, :16].cpu().numpy()[..., None], first.kernel, first.bias, 2, True)
+    assert np.abs(got - ref).max() <= 2e-5 * (1 + np.abs(ref).max())
+    heavy = enc.synthesis_transform.conv_layers()[7].layer          # Conv3DTranspose 16 -> 16 @ full resolution
+    t = rng.standard_normal((1, 6, 128, 128, 16)).astype(np.float32)
+    got = ops.conv3d(ctx, torch.from_numpy(t).to(ctx.device), heavy).cpu().numpy()
+    ref = oracle.conv3d_transpose(t, heavy.kernel, heavy.bias, 1, True)
+    assert np.abs(got - ref).max() <= 2e-5 * (1 + np.abs(ref).max())
