@@ -79,8 +79,8 @@ PCC_API int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
     PCC_CHECK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const bool fast_ok = w_packed != nullptr && pcc_conv_mfma_supported(d) == 1;
-    if (d->impl == PCC_IMPL_MFMA) {
-        PCC_REQUIRE(fast_ok, "pcc_conv3d: PCC_IMPL_MFMA requested but shape not covered or w_packed NULL");
+    if (d->impl == PCC_IMPL_MFMA || d->impl == PCC_IMPL_WINOGRAD) {
+        PCC_REQUIRE(fast_ok, "pcc_conv3d: PCC_IMPL_MFMA/WINOGRAD requested but shape not covered or w_packed NULL");
         return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
     }
     if (d->impl == PCC_IMPL_AUTO && fast_ok) return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);

@@ -83,6 +83,51 @@ def test_mfma_conv_matches_oracle(ctx, oracle, case):
     _run(ctx, oracle, N, D, H, W, cin, cout, k, s, tr, True, True, cout > 1, L.PCC_IMPL_MFMA, seed=3)
 
 
+WINO_CASES = [
+    # N, D, H, W, transposed, bias, relu, residual
+    (2, 6, 16, 16, False, True, True, True), (1, 5, 32, 16, True, True, True, True), (3, 1, 16, 32, False, False, False, False),
+    (1, 2, 16, 16, True, True, False, False), (1, 32, 16, 16, True, True, True, True),     # last: z split over workgroups
+    (2, 9, 48, 32, False, False, True, True),
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_winograd_conv_matches_oracle(ctx, oracle, case):
+    """conv_wino.hip: F(2x2,3x3) in x-y + direct z taps, same stated tolerance as the direct kernels."""
+    N, D, H, W, tr, bias, relu, res = case
+    _run(ctx, oracle, N, D, H, W, 16, 16, 3, 1, tr, bias, relu, res, L.PCC_IMPL_WINOGRAD, seed=21)
+
+
+def test_winograd_is_deterministic_batch_invariant_and_close_to_direct(ctx):
+    rng = np.random.default_rng(12)
+    w = (rng.standard_normal((3, 3, 3, 16, 16)) / 20).astype(np.float32)
+    layer = ops.ConvLayer(w, rng.standard_normal(16).astype(np.float32), 1, True, True)
+    x = torch.from_numpy(rng.standard_normal((5, 12, 32, 32, 16)).astype(np.float32)).to(ctx.device)
+    a = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_WINOGRAD)
+    b = ops.conv3d(ctx, x[3:4].contiguous(), layer, impl=L.PCC_IMPL_WINOGRAD)      # different z split / grid
+    c = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_WINOGRAD)
+    d = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
+    e = ops.conv3d(ctx, x, layer)                                                  # AUTO picks Winograd here
+    torch.cuda.synchronize()
+    assert torch.equal(a, c) and torch.equal(a[3:4], b) and torch.equal(a, e)
+    assert (a - d).abs().max().item() <= TOL * (1 + d.abs().max().item())
+    with pytest.raises(AssertionError):
+        ops.conv3d(ctx, x[:, :, :8, :8].contiguous(), layer, impl=L.PCC_IMPL_WINOGRAD)   # H, W not multiples of 16
+
+
+def test_winograd_concat_offset(ctx, oracle):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((1, 4, 16, 16, 16)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 16, 16)) / 20).astype(np.float32)
+    layer = ops.ConvLayer(w, None, 1, False, False)
+    out = torch.zeros((1, 4, 16, 16, 32), device=ctx.device)
+    ops.conv3d(ctx, torch.from_numpy(x).to(ctx.device), layer, out=out, out_coffset=12, impl=L.PCC_IMPL_WINOGRAD)
+    ref = oracle.conv3d(x, w)
+    got = out.cpu().numpy()
+    assert np.abs(got[..., 12:28] - ref).max() < 1e-4
+    assert np.all(got[..., :12] == 0) and np.all(got[..., 28:] == 0)
+
+
 def test_mfma_batch_partial_tiles_and_plain(ctx, oracle):
     # dims that are not multiples of the tile (partial tiles), batch > 1, no bias/relu/residual
     _run(ctx, oracle, 3, 5, 10, 16, 16, 16, 3, 1, False, False, False, False, L.PCC_IMPL_MFMA, seed=5)
