@@ -22,8 +22,8 @@
 // tiles.  LDS: U + a ring of 3 input planes 18x18x16ch (x de-interleaved by parity so that the stride-2 tile
 // origins become unit stride; 16-byte slots XOR-swizzled by voxel -> conflict-free ds_read_b128).
 // Software pipeline over 12 row slots (dz, py) of 16 MFMAs: under the MFMAs of plane s, plane s+1 is read
-// from LDS and transformed, plane s+2 is fetched global->registers->LDS, and the output plane completed by
-// the dz=2 rows is reduced and stored.  One barrier per step.
+// from LDS and transformed, plane s+2 is fetched global->LDS directly (buffer_load ... lds), and the output plane
+// completed by the dz=2 rows is reduced and stored.  One barrier per step.
 #include <cstdlib>
 #include <type_traits>
 
@@ -53,11 +53,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 constexpr int NT = 256;
 constexpr int PLANE_VOX = 18 * 18;
-constexpr int PLANE_BYTES = PLANE_VOX * 64;            // 20736
+constexpr int PLANE_ITEMS = PLANE_VOX * 4;             // float4 slots per plane (1296)
+constexpr int CHUNKS = (PLANE_ITEMS + 63) / 64;        // 21 wave-sized (1 KB) chunks; the last one is padding beyond slot 1295
+constexpr int PLANE_BYTES = CHUNKS * 1024;             // 21504: three planes end below 64 KB -> every plane offset is a DS immediate
+constexpr int U_BASE = 3 * PLANE_BYTES;
 constexpr int U_BYTES = 48 * 1024;                     // 3 z taps x 16 points x 64 lanes x float4
-constexpr int LDS_BYTES = U_BYTES + 3 * PLANE_BYTES;   // 111360
-constexpr int PLANE_ITEMS = PLANE_VOX * 4;             // float4 items per plane
-constexpr int ITEMS = (PLANE_ITEMS + NT - 1) / NT;     // 6 per thread and plane
+constexpr int LDS_BYTES = U_BASE + U_BYTES;            // 113664
+constexpr int ITEMS = 6;                               // chunks per wave: wave w stages chunks 5w .. 5w+5 (5, 10, 15 twice: same data)
 
 struct WinoArgs {
     const float* in;
@@ -70,22 +72,44 @@ struct WinoArgs {
     int flags, ocs, oco;
 };
 
-// B^T d B on a 4x4 array of float4 (4 input channels each): along x, then along y
-__device__ __forceinline__ void transform_x(f32x4 (&P)[16]) {
+// Measured on MI355X (tools/ubench/mfma_valu.hip): a wave's VALU instructions do NOT overlap with its own fp32 MFMAs
+// (v_mfma_f32_16x16x4_f32 runs at the packed-FMA rate of the same SIMD): every VALU op costs ~5 cycles of MFMA time,
+// v_mov / v_accvgpr_read ~8.  Hence: packed adds everywhere (the compiler turns a-b into two scalar v_sub), no
+// register copies, no per-lane address arithmetic in the loop.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
+// B^T along x, in place, on a 4x4 array of float4 (4 input channels each)
+__device__ __forceinline__ void transform_x_rows(f32x4 (&P)[16], int y0, int y1) {
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
+    for (int y = y0; y < y1; ++y) {
         const f32x4 d0 = P[y * 4 + 0], d1 = P[y * 4 + 1], d2 = P[y * 4 + 2], d3 = P[y * 4 + 3];
-        P[y * 4 + 0] = d0 - d2; P[y * 4 + 1] = d1 + d2; P[y * 4 + 2] = d2 - d1; P[y * 4 + 3] = d1 - d3;
+        P[y * 4 + 0] = sub4(d0, d2); P[y * 4 + 1] = add4(d1, d2); P[y * 4 + 2] = sub4(d2, d1); P[y * 4 + 3] = sub4(d1, d3);
     }
 }
-__device__ __forceinline__ void transform_y(f32x4 (&P)[16]) {
+// B^T along y, one output row: V[r][x] from the x-transformed patch
+__device__ __forceinline__ void transform_y_row(f32x4 (&V)[16], const f32x4 (&P)[16], int r) {
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-        const f32x4 d0 = P[0 + x], d1 = P[4 + x], d2 = P[8 + x], d3 = P[12 + x];
-        P[0 + x] = d0 - d2; P[4 + x] = d1 + d2; P[8 + x] = d2 - d1; P[12 + x] = d1 - d3;
+        if (r == 0) V[x] = sub4(P[x], P[8 + x]);
+        else if (r == 1) V[4 + x] = add4(P[4 + x], P[8 + x]);
+        else if (r == 2) V[8 + x] = sub4(P[8 + x], P[4 + x]);
+        else V[12 + x] = sub4(P[4 + x], P[12 + x]);
     }
 }
 
+template <bool RELU, bool CLIP>
 __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +126,9 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     const int nsteps = a.zlen + 2;             // input planes zb-1 .. zb+zlen
     const unsigned HW64 = (unsigned)a.H * a.W * 64u;
     const unsigned img_bytes = (unsigned)a.D * HW64;
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in + (size_t)n * a.D * a.H * a.W * 16, img_bytes);
+    const float* in_n = a.in + (size_t)n * a.D * a.H * a.W * 16;
+    // plane-sized descriptors: z validity selects the descriptor (wave-uniform), y/x validity is the per-lane offset
+    auto plane_rsrc = [&](int z) { const bool ok = (unsigned)z < (unsigned)a.D; return make_rsrc(in_n + (ok ? (size_t)z * a.H * a.W * 16 : 0), ok ? HW64 : 0u); };
 
     // ---- U -> LDS (12 float4 per thread)
     {
@@ -111,27 +137,28 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
         for (int i = 0; i < 12; ++i) tmp[i] = buf_load4(ru, (unsigned)(i * NT + tid) * 16u, 0);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) ldsw((unsigned)(i * NT + tid) * 16u, tmp[i]);
+        for (int i = 0; i < 12; ++i) ldsw((unsigned)(U_BASE + (i * NT + tid) * 16), tmp[i]);
     }
 
-    // ---- staging items of one plane: global offset inside a z-plane (or OOB) and swizzled LDS slot
-    unsigned rel[ITEMS], wr[ITEMS];
+    // ---- staging: global -> LDS directly (buffer_load ... lds, no registers, no ds_write).  The LDS side of such a load
+    //      is linear (M0 base + lane*16), so the XOR swizzle and the x de-interleave are applied on the GLOBAL side:
+    //      lane L of chunk c fetches whatever belongs into LDS slot 64c + L.
+    unsigned rel[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        const int idx = it * NT + tid;
-        const int yrow = idx / 72, rem = idx - yrow * 72, xi = rem >> 2, c4 = rem & 3;
+        const int slot = (wave * 5 + it) * 64 + lane;
+        const int v = slot >> 2, c4 = (slot & 3) ^ ((v >> 1) & 3);
+        const int yrow = v / 18, r = v - yrow * 18, par = r >= 9 ? 1 : 0, col = r - 9 * par, xi = 2 * col + par;
         const int y = Y0 - 1 + yrow, x = X0 - 1 + xi;
-        const bool ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
-        rel[it] = ok ? (unsigned)((y * a.W + x) * 64 + c4 * 16) : kOOB;
-        const int v = (yrow * 2 + (xi & 1)) * 9 + (xi >> 1);
-        wr[it] = (unsigned)(U_BYTES + v * 64 + ((c4 ^ ((v >> 1) & 3)) << 4));
-        if (idx >= PLANE_ITEMS) { rel[it] = rel[it - 1]; wr[it] = wr[it - 1]; }   // tail: repeat the previous item (same data, same slot)
+        const bool ok = v < PLANE_VOX && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        rel[it] = ok ? (unsigned)((y * a.W + x) * 64 + c4 * 16) : kOOB;      // OOB lanes write zeros (SAME padding / chunk padding)
     }
-    auto load_plane = [&](f32x4 (&dst)[ITEMS], int z) __attribute__((always_inline)) {
-        const bool zok = (unsigned)z < (unsigned)a.D;
-        const unsigned zflag = zok ? 0u : kOOB, zoff = zok ? (unsigned)z * HW64 : 0u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto stage_plane = [&](unsigned plane_off, int z) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rp = plane_rsrc(z);
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) dst[it] = buf_load4(rin, rel[it] | zflag, zoff);
+        for (int it = 0; it < ITEMS; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + plane_off + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
     };
 
     // ---- per-lane patch read addresses (ring slot 0), tile of this lane
@@ -143,9 +170,9 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
             const int v = 36 * TY + 18 * dy + 9 * (dx & 1) + TX + (dx >> 1);
-            ra[dy * 4 + dx] = (unsigned)(U_BYTES + v * 64 + ((g ^ ((v >> 1) & 3)) << 4));
+            ra[dy * 4 + dx] = (unsigned)(v * 64 + ((g ^ ((v >> 1) & 3)) << 4));
         }
-    const unsigned ua = (unsigned)lane * 16u;
+    const unsigned ua = (unsigned)(U_BASE + lane * 16);
 
     // ---- epilogue addressing: lane writes couts 4g..4g+3 of the 2x2 voxels of its tile
     const int ox0 = X0 + 2 * TX, oy0 = Y0 + 2 * TY;
@@ -158,38 +185,32 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     }
     const unsigned HWO = (unsigned)a.H * a.W * (unsigned)a.ocs * 4u;
     const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + (size_t)n * a.D * a.H * a.W * 16 : a.in, has_res ? img_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + (size_t)n * a.D * a.H * a.W * a.ocs, (unsigned)a.D * HWO);
+    const float* res_n = has_res ? a.res + (size_t)n * a.D * a.H * a.W * 16 : a.in;
+    float* out_n = a.out + (size_t)n * a.D * a.H * a.W * a.ocs;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bias4 = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + g * 4) : zero4;
-    const float relu_lo = (a.flags & PCC_CONV_RELU) ? 0.f : -__builtin_inff();
-    const float clip_lo = (a.flags & PCC_CONV_CLIP01) ? 0.f : -__builtin_inff();
-    const float clip_hi = (a.flags & PCC_CONV_CLIP01) ? 1.f : __builtin_inff();
 
-    // ---- prologue: input planes s = 0, 1 (z = zb-1, zb) -> ring slots 0, 1;  V(0) -> registers
-    f32x4 stg[ITEMS];
-    {
-        f32x4 stg1[ITEMS];
-        load_plane(stg, zb - 1);
-        load_plane(stg1, zb);
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) { ldsw(wr[it], stg[it]); ldsw(wr[it] + PLANE_BYTES, stg1[it]); }
-    }
+    // ---- prologue: input planes s = 0, 1 (z = zb-1, zb) -> ring slots 0, 1
+    stage_plane(0, zb - 1);
+    stage_plane(PLANE_BYTES, zb);
     __syncthreads();
 
-    f32x4 Vc[16], Vn[16];       // transformed patch of the current / next input plane
+    f32x4 Vc[16];               // B^T d B of the current input plane (B operand of the MFMAs)
+    f32x4 Vn[16];               // next plane: raw patch -> x-transformed; its y-transform is written row by row into Vc
     f32x4 Ub[2][4];
     f32x4 acc[3][16];           // three output planes in flight
     f32x4 S[2][2];              // A^T-reduced 2x2 outputs of the finished plane
     f32x4 resv[4], ost[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Vc[i] = ldsr(ra[i]);
-    transform_x(Vc);
-    transform_y(Vc);
+    for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i]);
+    transform_x_rows(Vn, 0, 4);
+    transform_y_row(Vc, Vn, 0);
+    transform_y_row(Vc, Vn, 1);
+    transform_y_row(Vc, Vn, 2);          // row 3 follows in slot 0 of the first step
 #pragma unroll
     for (int px = 0; px < 4; ++px) Ub[0][px] = ldsr(ua + (unsigned)((2 * 16 + px) * 1024));   // first row: dz = 2, py = 0
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }
+    for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }   // (planes finishing at s < 2 are never stored)
 
     // one input plane: s = step index (input plane z = zb-1+s), PH = s mod 3
     auto step = [&](auto ph_tag, int s) __attribute__((always_inline)) {
@@ -198,7 +219,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
         constexpr unsigned slotW = (unsigned)((PH + 2) % 3) * PLANE_BYTES;   // plane s+2 (written)
         constexpr int AF = PH;                                               // acc slot of the plane finished by dz = 2
         const int zo = zb - 2 + s;                                           // that plane (valid when s >= 2)
-        const unsigned sflag = s >= 2 ? 0u : kOOB;
+        const bool zo_ok = s >= 2;
+        // plane-sized descriptors of the finished output plane; zero-sized (loads return 0, stores are dropped) while s < 2
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(res_n + (zo_ok && has_res ? (size_t)zo * a.H * a.W * 16 : 0), zo_ok && has_res ? HW64 : 0u);
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(out_n + (zo_ok ? (size_t)zo * a.H * a.W * a.ocs : 0), zo_ok ? HWO : 0u);
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int dz = 2 - (j >> 2), py = j & 3;
@@ -214,62 +238,68 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {
-                    const f32x4 c = (dz == 0 && kk == 0) ? zero4 : acc[as][py * 4 + px];
+                    // a new output plane starts from 0, except point (1,1) which enters all four outputs with weight +1
+                    // and therefore carries the bias for free
+                    const f32x4 c = (dz == 0 && kk == 0) ? ((py == 1 && px == 1) ? bias4 : zero4) : acc[as][py * 4 + px];
                     acc[as][py * 4 + px] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ub[j & 1][px][kk], Vc[py * 4 + px][kk], c, 0, 0, 0);
                 }
-            // (3) everything else, spread over the slots
-            if (j == 0) {
-                load_plane(stg, zb - 1 + s + 2);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) resv[q] = buf_load4(rres, rvo[q] | sflag, s >= 2 ? (unsigned)zo * HW64 : 0u);
+            // (3) everything else, spread over the slots.  Vc row r is last read by the MFMAs of slot 8+r, so the rows of
+            //     the next plane are written in slots 9, 10, 11 and (row 3) slot 0 of the next step: no register copies.
+            if (j == 0) transform_y_row(Vc, Vn, 3);
+            else if (j == 1) {
+                stage_plane(slotW, zb - 1 + s + 2);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i] + slotN);
+            } else if (j == 2) transform_x_rows(Vn, 0, 2);
+            else if (j == 3) transform_x_rows(Vn, 2, 4);
+            else if (j == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) resv[q] = buf_load4(rres, rvo[q], 0);
             }
-            else if (j == 1) transform_x(Vn);
-            else if (j == 2) transform_y(Vn);
             else if (j >= 5 && j <= 8) {
                 // A^T along x on row r of the finished plane, accumulate A^T along y
                 const int r = j - 5;
                 const f32x4 m0 = acc[AF][r * 4 + 0], m1 = acc[AF][r * 4 + 1], m2 = acc[AF][r * 4 + 2], m3 = acc[AF][r * 4 + 3];
-                const f32x4 r0 = m0 + m1 + m2, r1 = m1 - m2 - m3;
+                const f32x4 r0 = add4(add4(m0, m1), m2), r1 = sub4(sub4(m1, m2), m3);
                 if (r == 0) { S[0][0] = r0; S[0][1] = r1; }
-                else if (r == 1) { S[0][0] += r0; S[0][1] += r1; S[1][0] = r0; S[1][1] = r1; }
-                else if (r == 2) { S[0][0] += r0; S[0][1] += r1; S[1][0] -= r0; S[1][1] -= r1; }
-                else { S[1][0] -= r0; S[1][1] -= r1; }
-                if (j == 8) {
-#pragma unroll
-                    for (int it = 0; it < ITEMS; ++it) ldsw(wr[it] + slotW, stg[it]);
-                }
+                else if (r == 1) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = r0; S[1][1] = r1; }
+                else if (r == 2) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
+                else { S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
             } else if (j == 9) {
-                // epilogue of the finished plane: bias, ReLU, residual, clip (all branch-free), float4 stores
-                // (dropped by the range check while s < 2)
-                const unsigned zoff = s >= 2 ? (unsigned)zo * HWO : 0u;
+                // epilogue of the finished plane: bias, ReLU, residual, clip, float4 stores
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 o = S[q >> 1][q & 1] + bias4;
+                    f32x4 o = S[q >> 1][q & 1];                  // (bias already inside, see the dz = 0 rows)
+                    if (RELU) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], relu_lo);
-                    o += resv[q];     // zeros without PCC_CONV_ADD (zero-sized buffer)
+                        for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
+                    }
+                    o = add4(o, resv[q]);     // zeros without PCC_CONV_ADD (zero-sized buffer)
+                    if (CLIP) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], clip_lo), clip_hi);
+                        for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
+                    }
                     ost[q] = o;
                 }
-                // gfx950: a buffer_store_dwordx4 whose soffset is an SGPR reads its data late; a VALU write to the data
-                // registers in the next issue slots corrupts the last dword of the last lanes (seen as out[q].w <-
-                // out[q+1].w).  The compiler only guards the immediate-soffset form, so: immediate soffset (z offset
-                // folded into the address) AND the data registers stay live until the next slot.
+                // gfx950: a buffer_store_dwordx4 reads its data registers late; a VALU write to them in the next issue
+                // slots corrupts the last dword of the last lanes (seen as out[q].w <- out[q+1].w).  The compiler only
+                // guards the immediate-soffset form with one wait state, so the data registers are kept live (and
+                // therefore unwritten) until the next slot.
 #pragma unroll
-                for (int q = 0; q < 4; ++q) buf_store4(rout, ost[q], (ovo[q] + zoff) | sflag, 0);
+                for (int q = 0; q < 4; ++q) buf_store4(rout, ost[q], ovo[q], 0);
+                transform_y_row(Vc, Vn, 0);
             } else if (j == 10) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(ost[q]));
-            }
+                transform_y_row(Vc, Vn, 1);
+            } else if (j == 11) transform_y_row(Vc, Vn, 2);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // V(s+1) becomes the current patch (all MFMAs that read Vc are issued); planes in LDS are published
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Vc[i] = Vn[i];
-        __syncthreads();
+        // The LDS-direct loads of plane s+2 (slot 1) must have landed before the barrier publishes them to the other
+        // waves; the compiler only orders them against this wave's own LDS reads.  vmcnt counts in issue order: the 4
+        // residual loads (slot 4) and 4 stores (slot 9) issued later may stay in flight.
+        __builtin_amdgcn_s_waitcnt(0x0F78);      // vmcnt(8) expcnt(7) lgkmcnt(15)
+        __syncthreads();     // plane s+2 is published; nobody still reads plane s+1
     };
 
     for (int s = 0; s < nsteps; s += 3) {
@@ -311,10 +341,16 @@ int pcc_conv16_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
     const int nwg = base * zs;
     static thread_local bool configured = false;
     if (!configured) {
-        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         configured = true;
     }
-    hipLaunchKernelGGL(conv16_wino_kernel, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a, nwg);
+    const bool relu = (d->flags & PCC_CONV_RELU) != 0, clip = (d->flags & PCC_CONV_CLIP01) != 0;
+    auto kern = relu ? (clip ? conv16_wino_kernel<true, true> : conv16_wino_kernel<true, false>)
+                     : (clip ? conv16_wino_kernel<false, true> : conv16_wino_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a, nwg);
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;
 }
