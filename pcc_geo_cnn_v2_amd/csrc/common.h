@@ -47,8 +47,9 @@ int pcc_conv3d_generic(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
                        const float* bias, const float* residual, float* out, hipStream_t st);
 int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed,
                     const float* bias, const float* residual, float* out, hipStream_t st);
-// Winograd F(2x2,3x3) (x,y) + direct z path for 16->16 k3 stride-1 layers (conv_wino.hip)
+// Winograd F(2x2,3x3) (x,y) + direct z path for 16->16 and 32->32 k3 stride-1 layers (conv_wino.hip)
 bool pcc_wino_eligible(const pcc_conv_desc* d);
-int pcc_conv16_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed,
-                    const float* bias, const float* residual, float* out, hipStream_t st);
-constexpr int PCC_WINO_U_FLOATS = 48 * 64 * 4;   // [z tap][point][lane][cin quad member]
+int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed,
+                  const float* bias, const float* residual, float* out, hipStream_t st);
+constexpr int PCC_WINO_U_FLOATS = 48 * 64 * 4;   // per (cin group, cout group): [z tap][point][lane][cin quad member]
+inline bool pcc_wino_channels(int cin, int cout) { return cin == cout && (cin == 16 || cin == 32); }

@@ -1224,14 +1224,16 @@ PCC_API int pcc_conv_mfma_supported(const pcc_conv_desc* d) {
     return make_plan(d).kind != K_NONE ? 1 : 0;
 }
 
+#define NGROUPS(c) ((c) / 16)
 PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
     if (!d) return 0;
     const Plan p = make_plan(d);
     const size_t k3 = (size_t)d->k * d->k * d->k;
     switch (p.kind) {
         case K_FWD:
-            // 16->16 k3 stride-1 layers also carry the Winograd-transformed weights (conv_wino.hip)
-            if (d->Cin == 16 && d->Cout == 16 && d->k == 3 && d->stride == 1) return k3 * 256 + PCC_WINO_U_FLOATS;
+            // 16->16 / 32->32 k3 stride-1 layers also carry the Winograd-transformed weights (conv_wino.hip)
+            if (pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && d->stride == 1)
+                return k3 * d->Cin * d->Cout + (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_U_FLOATS;
             return k3 * d->Cin * d->Cout;
         case K_TR2: return k3 * d->Cin * d->Cout;
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
@@ -1265,18 +1267,20 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                             pk[((((size_t)g * k * k * k + tap) * NCT + ct) * 64 + lane) * 4 + j] =
                                 Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
             }
-        if (Cin == 16 && Cout == 16 && k == 3 && d->stride == 1) {
-            // U[dz][py][px][lane][kk] = (G (x) G) g_dz  for cin = 4*(lane>>4) + kk, cout = lane & 15; double precision
+        if (pcc_wino_channels(Cin, Cout) && k == 3 && d->stride == 1) {
+            // [cin group][cout group] U[dz][py][px][lane][kk] = (G (x) G) g_dz  for cin = 16 cig + 4*(lane>>4) + kk,
+            // cout = 16 cog + (lane & 15); double precision
             static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-            float* u = pk + 27 * 256;
-            for (int kz = 0; kz < 3; ++kz) for (int py = 0; py < 4; ++py) for (int px = 0; px < 4; ++px)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int kk = 0; kk < 4; ++kk) {
-                        double s = 0;
-                        for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
-                            s += G[py][ky] * G[px][kx] * (double)Wf(kz, ky, kx, 4 * (lane >> 4) + kk, lane & 15);
-                        u[((size_t)((kz * 4 + py) * 4 + px) * 64 + lane) * 4 + kk] = (float)s;
-                    }
+            float* u = pk + (size_t)27 * Cin * Cout;
+            for (int cig = 0; cig < NG; ++cig) for (int cog = 0; cog < NCT; ++cog)
+                for (int kz = 0; kz < 3; ++kz) for (int py = 0; py < 4; ++py) for (int px = 0; px < 4; ++px)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int kk = 0; kk < 4; ++kk) {
+                            double s = 0;
+                            for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
+                                s += G[py][ky] * G[px][kx] * (double)Wf(kz, ky, kx, 16 * cig + 4 * (lane >> 4) + kk, 16 * cog + (lane & 15));
+                            u[(((size_t)(cig * NCT + cog) * 48 + (kz * 4 + py) * 4 + px) * 64 + lane) * 4 + kk] = (float)s;
+                        }
         }
     } else if (p.kind == K_TR2) {
         // consumption order of conv_tr2_kernel: [parity class (pz,py,px)][taps of the class (kz,ky,kx)][g][ct][lane][j]
@@ -1335,13 +1339,14 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 #define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st);
     if (p.kind == K_FWD) {
         const int fs = p.flip ? 1 : s;
-        if (ci == 16 && co == 16 && k == 3 && fs == 1) {
+        if (pcc_wino_channels(ci, co) && k == 3 && fs == 1) {
             static const bool no_wino = getenv("PCC_NO_WINOGRAD") != nullptr;
-            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !no_wino);
-            if (want && pcc_wino_eligible(d)) return pcc_conv16_wino(ctx, d, in, w_packed + 27 * 256, bias, residual, out, st);
+            static const bool no_wino32 = getenv("PCC_NO_WINOGRAD32") != nullptr;
+            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !no_wino && !(ci == 32 && (no_wino32 || d->D < 32)));
+            if (want && pcc_wino_eligible(d)) return pcc_conv_wino(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, residual, out, st);
             PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD needs W and H multiples of 16");
         } else {
-            PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD covers 16->16 k3 stride-1 layers only");
+            PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD covers 16->16 / 32->32 k3 stride-1 layers only");
         }
         PCC_CASE_FWD(16, 16, 3, 1) PCC_CASE_FWD(32, 32, 3, 1) PCC_CASE_FWD(64, 64, 3, 1)
         PCC_CASE_FWD(16, 32, 3, 2) PCC_CASE_FWD(32, 64, 3, 2) PCC_CASE_FWD(64, 64, 3, 2)

@@ -63,13 +63,16 @@ constexpr int ITEMS = 6;                               // chunks per wave: wave 
 
 struct WinoArgs {
     const float* in;
-    const float* u;     // packed transformed weights
+    const float* u;     // packed transformed weights of this cin group: [cout group][48][64][4]
     const float* bias;
     const float* res;
     float* out;
     int N, D, H, W;
     int nty, ntx, zsplit, zlen;
+    int nco;            // cout groups of 16 handled by this launch (grid dimension)
     int flags, ocs, oco;
+    int ics, ico;       // input channel stride / offset of this launch's 16-channel cin group
+    int rcs;            // residual channel stride (its channel offset follows the cout group)
 };
 
 // Measured on MI355X (tools/ubench/mfma_valu.hip): a wave's VALU instructions do NOT overlap with its own fp32 MFMAs
@@ -109,7 +112,7 @@ __device__ __forceinline__ void transform_y_row(f32x4 (&V)[16], const f32x4 (&P)
     }
 }
 
-template <bool RELU, bool CLIP>
+template <bool RELU, bool CLIP, bool PRE>
 __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,21 +121,22 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     auto ldsw = [&](unsigned off, const f32x4& v) { *reinterpret_cast<f32x4*>(smem + off) = v; };
 
     int wg = xcd_remap(blockIdx.x, nwg);
+    const int cog = wg % a.nco; wg /= a.nco;       // cout group: neighbours in the grid share their input planes in L2
     const int tx_ = wg % a.ntx; wg /= a.ntx;
     const int ty_ = wg % a.nty; wg /= a.nty;
     const int zs = wg % a.zsplit;
     const int n = wg / a.zsplit;
     const int X0 = tx_ * 16, Y0 = ty_ * 16, zb = zs * a.zlen;
     const int nsteps = a.zlen + 2;             // input planes zb-1 .. zb+zlen
-    const unsigned HW64 = (unsigned)a.H * a.W * 64u;
-    const unsigned img_bytes = (unsigned)a.D * HW64;
-    const float* in_n = a.in + (size_t)n * a.D * a.H * a.W * 16;
+    const size_t HW = (size_t)a.H * a.W;
+    const unsigned HWI = (unsigned)(HW * a.ics * 4), HWR = (unsigned)(HW * a.rcs * 4);      // bytes per z-plane
+    const float* in_n = a.in + (size_t)n * a.D * HW * a.ics + a.ico;
     // plane-sized descriptors: z validity selects the descriptor (wave-uniform), y/x validity is the per-lane offset
-    auto plane_rsrc = [&](int z) { const bool ok = (unsigned)z < (unsigned)a.D; return make_rsrc(in_n + (ok ? (size_t)z * a.H * a.W * 16 : 0), ok ? HW64 : 0u); };
+    auto plane_rsrc = [&](int z) { const bool ok = (unsigned)z < (unsigned)a.D; return make_rsrc(in_n + (ok ? (size_t)z * HW * a.ics : 0), ok ? HWI : 0u); };
 
     // ---- U -> LDS (12 float4 per thread)
     {
-        const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u, (unsigned)U_BYTES);
+        const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u + (size_t)cog * (U_BYTES / 4), (unsigned)U_BYTES);
         f32x4 tmp[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) tmp[i] = buf_load4(ru, (unsigned)(i * NT + tid) * 16u, 0);
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
         const int yrow = v / 18, r = v - yrow * 18, par = r >= 9 ? 1 : 0, col = r - 9 * par, xi = 2 * col + par;
         const int y = Y0 - 1 + yrow, x = X0 - 1 + xi;
         const bool ok = v < PLANE_VOX && y >= 0 && y < a.H && x >= 0 && x < a.W;
-        rel[it] = ok ? (unsigned)((y * a.W + x) * 64 + c4 * 16) : kOOB;      // OOB lanes write zeros (SAME padding / chunk padding)
+        rel[it] = ok ? (unsigned)(((y * a.W + x) * a.ics + c4 * 4) * 4) : kOOB;   // OOB lanes write zeros (SAME padding / chunk padding)
     }
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto stage_plane = [&](unsigned plane_off, int z) __attribute__((always_inline)) {
@@ -180,15 +184,15 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const unsigned vox = (unsigned)((oy0 + (q >> 1)) * a.W + ox0 + (q & 1));
-        ovo[q] = (vox * (unsigned)a.ocs + (unsigned)a.oco + 4u * g) * 4u;
-        rvo[q] = (vox * 16u + 4u * g) * 4u;
+        ovo[q] = (vox * (unsigned)a.ocs + (unsigned)a.oco + 16u * cog + 4u * g) * 4u;
+        rvo[q] = (vox * (unsigned)a.rcs + 16u * cog + 4u * g) * 4u;
     }
-    const unsigned HWO = (unsigned)a.H * a.W * (unsigned)a.ocs * 4u;
+    const unsigned HWO = (unsigned)(HW * a.ocs * 4);
     const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
-    const float* res_n = has_res ? a.res + (size_t)n * a.D * a.H * a.W * 16 : a.in;
-    float* out_n = a.out + (size_t)n * a.D * a.H * a.W * a.ocs;
+    const float* res_n = has_res ? a.res + (size_t)n * a.D * HW * a.rcs : a.in;
+    float* out_n = a.out + (size_t)n * a.D * HW * a.ocs;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 bias4 = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + g * 4) : zero4;
+    const f32x4 bias4 = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + 16 * cog + g * 4) : zero4;
 
     // ---- prologue: input planes s = 0, 1 (z = zb-1, zb) -> ring slots 0, 1
     stage_plane(0, zb - 1);
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     f32x4 Ub[2][4];
     f32x4 acc[3][16];           // three output planes in flight
     f32x4 S[2][2];              // A^T-reduced 2x2 outputs of the finished plane
-    f32x4 resv[4], ost[4];
+    f32x4 resv[4], prev[4], ost[4];
 #pragma unroll
     for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i]);
     transform_x_rows(Vn, 0, 4);
@@ -221,8 +225,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
         const int zo = zb - 2 + s;                                           // that plane (valid when s >= 2)
         const bool zo_ok = s >= 2;
         // plane-sized descriptors of the finished output plane; zero-sized (loads return 0, stores are dropped) while s < 2
-        const __amdgpu_buffer_rsrc_t rres = make_rsrc(res_n + (zo_ok && has_res ? (size_t)zo * a.H * a.W * 16 : 0), zo_ok && has_res ? HW64 : 0u);
-        const __amdgpu_buffer_rsrc_t rout = make_rsrc(out_n + (zo_ok ? (size_t)zo * a.H * a.W * a.ocs : 0), zo_ok ? HWO : 0u);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(res_n + (zo_ok && has_res ? (size_t)zo * HW * a.rcs : 0), zo_ok && has_res ? HWR : 0u);
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(out_n + (zo_ok ? (size_t)zo * HW * a.ocs : 0), zo_ok ? HWO : 0u);
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int dz = 2 - (j >> 2), py = j & 3;
@@ -255,6 +259,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             else if (j == 4) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) resv[q] = buf_load4(rres, rvo[q], 0);
+                if (PRE) {   // partial sums of the previous cin groups, accumulated in place in `out` (same lane, same address)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) prev[q] = buf_load4(rout, ovo[q], 0);
+                }
             }
             else if (j >= 5 && j <= 8) {
                 // A^T along x on row r of the finished plane, accumulate A^T along y
@@ -270,6 +278,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 o = S[q >> 1][q & 1];                  // (bias already inside, see the dz = 0 rows)
+                    if (PRE) o = add4(o, prev[q]);
                     if (RELU) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
@@ -297,8 +306,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
         }
         // The LDS-direct loads of plane s+2 (slot 1) must have landed before the barrier publishes them to the other
         // waves; the compiler only orders them against this wave's own LDS reads.  vmcnt counts in issue order: the 4
-        // residual loads (slot 4) and 4 stores (slot 9) issued later may stay in flight.
-        __builtin_amdgcn_s_waitcnt(0x0F78);      // vmcnt(8) expcnt(7) lgkmcnt(15)
+        // residual (+4 partial-sum) loads of slot 4 and the 4 stores of slot 9 issued later may stay in flight.
+        __builtin_amdgcn_s_waitcnt(PRE ? 0x0F7C : 0x0F78);      // vmcnt(8 or 12) expcnt(7) lgkmcnt(15)
         __syncthreads();     // plane s+2 is published; nobody still reads plane s+1
     };
 
@@ -314,43 +323,55 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 using namespace pccwino;
 
 bool pcc_wino_eligible(const pcc_conv_desc* d) {
-    if (d->Cin != 16 || d->Cout != 16 || d->k != 3 || d->stride != 1) return false;
+    if (d->Cin != d->Cout || (d->Cin != 16 && d->Cin != 32) || d->k != 3 || d->stride != 1) return false;
     if (d->W % 16 || d->H % 16) return false;
-    if ((double)d->D * d->H * d->W * 64.0 >= 2147483648.0) return false;
     const int ocs = d->out_cstride ? d->out_cstride : d->Cout;
     if (ocs % 4 || d->out_coffset % 4) return false;
-    if ((double)d->D * d->H * d->W * ocs * 4.0 >= 2147483648.0) return false;
+    const double hw = (double)d->H * d->W;
+    if (hw * d->Cin * 4.0 >= 2147483648.0 || hw * ocs * 4.0 >= 2147483648.0) return false;     // one z-plane per buffer descriptor
     return true;
 }
 
-int pcc_conv16_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed, const float* bias,
-                    const float* residual, float* out, hipStream_t st) {
-    PCC_REQUIRE(pcc_wino_eligible(d), "pcc_conv16_wino: shape not covered");
+// Cin = Cout = 16 g: g x g sub-convolutions of 16 -> 16 channels.  One launch per cin group covers all cout groups
+// (grid dimension); the partial sums of the earlier cin groups are accumulated in place in `out` (template PRE), bias /
+// ReLU / residual / clip are applied by the last launch only.
+int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed, const float* bias,
+                  const float* residual, float* out, hipStream_t st) {
+    PCC_REQUIRE(pcc_wino_eligible(d), "pcc_conv_wino: shape not covered");
     WinoArgs a;
-    a.in = in; a.u = u_packed; a.bias = bias; a.res = residual; a.out = out;
+    a.in = in; a.bias = bias; a.res = residual; a.out = out;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
     a.nty = d->H / 16; a.ntx = d->W / 16;
-    a.flags = d->flags;
     a.ocs = d->out_cstride ? d->out_cstride : d->Cout;
     a.oco = d->out_coffset;
+    const int G = d->Cin / 16;
+    a.nco = G; a.ics = d->Cin; a.rcs = d->Cout;
     // split z so that every CU gets a workgroup (each split pays the 48 KB U load and two halo planes)
-    const int base = d->N * a.nty * a.ntx;
+    const int base = d->N * a.nty * a.ntx * G;
     int zs = 1;
     while (base * zs < ctx->num_cu && d->D % (zs * 2) == 0 && d->D / (zs * 2) >= 8) zs *= 2;
     a.zsplit = zs; a.zlen = d->D / zs;
     const int nwg = base * zs;
+    typedef void (*kern_t)(WinoArgs, int);
+    static const kern_t kerns[8] = {conv16_wino_kernel<false, false, false>, conv16_wino_kernel<true, false, false>,
+                                    conv16_wino_kernel<false, true, false>,  conv16_wino_kernel<true, true, false>,
+                                    conv16_wino_kernel<false, false, true>,  conv16_wino_kernel<true, false, true>,
+                                    conv16_wino_kernel<false, true, true>,   conv16_wino_kernel<true, true, true>};
     static thread_local bool configured = false;
     if (!configured) {
-        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv16_wino_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        for (int i = 0; i < 8; ++i)
+            PCC_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         configured = true;
     }
-    const bool relu = (d->flags & PCC_CONV_RELU) != 0, clip = (d->flags & PCC_CONV_CLIP01) != 0;
-    auto kern = relu ? (clip ? conv16_wino_kernel<true, true> : conv16_wino_kernel<true, false>)
-                     : (clip ? conv16_wino_kernel<false, true> : conv16_wino_kernel<false, false>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a, nwg);
-    PCC_CHECK_HIP(hipGetLastError());
+    for (int ci = 0; ci < G; ++ci) {
+        const bool last = ci == G - 1;
+        a.u = u_packed + (size_t)ci * G * (U_BYTES / 4);
+        a.ico = 16 * ci;
+        a.flags = last ? d->flags : 0;
+        const bool relu = last && (d->flags & PCC_CONV_RELU), clip = last && (d->flags & PCC_CONV_CLIP01);
+        const kern_t kern = kerns[(relu ? 1 : 0) + (clip ? 2 : 0) + (ci > 0 ? 4 : 0)];
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a, nwg);
+        PCC_CHECK_HIP(hipGetLastError());
+    }
     return PCC_OK;
 }

@@ -91,11 +91,13 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize('ch', [16, 32])
 @pytest.mark.parametrize('case', WINO_CASES)
-def test_winograd_conv_matches_oracle(ctx, oracle, case):
-    """conv_wino.hip: F(2x2,3x3) in x-y + direct z taps, same stated tolerance as the direct kernels."""
+def test_winograd_conv_matches_oracle(ctx, oracle, case, ch):
+    """conv_wino.hip: F(2x2,3x3) in x-y + direct z taps, same stated tolerance as the direct kernels.
+    32 -> 32 runs as 2 x 2 sub-convolutions of 16 channels with in-place partial sums."""
     N, D, H, W, tr, bias, relu, res = case
-    _run(ctx, oracle, N, D, H, W, 16, 16, 3, 1, tr, bias, relu, res, L.PCC_IMPL_WINOGRAD, seed=21)
+    _run(ctx, oracle, N, D, H, W, ch, ch, 3, 1, tr, bias, relu, res, L.PCC_IMPL_WINOGRAD, seed=21)
 
 
 def test_winograd_is_deterministic_batch_invariant_and_close_to_direct(ctx):

@@ -14,7 +14,7 @@ for d in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_lds'):
     for f in glob.glob(os.path.join(src, d, '*counter_collection.csv')):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'conv16_pers' in r['Kernel_Name']:
+            if 'conv16_wino' in r['Kernel_Name'] or 'conv16_pers' in r['Kernel_Name']:
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
         for k, v in agg.items():
             pmc[k] = sum(v) / len(v)
@@ -24,7 +24,7 @@ fetch = pmc.get('FETCH_SIZE', float('nan')) * 1024 * 2   # KB -> B, x2: gfx950 F
 write = pmc.get('WRITE_SIZE', float('nan')) * 1024
 traffic = fetch + write
 simd_cycles = pmc.get('GRBM_GUI_ACTIVE', float('nan')) / 8 * 1024   # per-XCD cycles x 1024 SIMDs
-out = {'kernel': 'conv16_pers_kernel<2,8,4>, Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32',
+out = {'kernel': 'conv16_wino_kernel<relu,clip> (Winograd F(2x2,3x3)+direct z), Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32',
        'hbm_bytes_per_launch': traffic, 'fetch_bytes_corrected_x2': fetch, 'write_bytes': write,
        'algorithmic_bytes_per_launch': alg, 'traffic_over_algorithmic': traffic / alg,
        'l2_hit_rate': pmc.get('TCC_HIT_sum', 0) / max(pmc.get('TCC_HIT_sum', 0) + pmc.get('TCC_MISS_sum', 0), 1),
