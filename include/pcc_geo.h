@@ -61,7 +61,7 @@ int pcc_ctx_num_cu(pcc_ctx* ctx);
 #define PCC_IMPL_AUTO 0    /* MFMA implicit-GEMM when the shape is covered, else generic          */
 #define PCC_IMPL_GENERIC 1 /* direct convolution, any shape (reference-order fp32 FMA chain)      */
 #define PCC_IMPL_MFMA 2    /* force the direct MFMA implicit-GEMM path; PCC_ERR_ARG if not covered */
-#define PCC_IMPL_WINOGRAD 3 /* force Winograd F(2x2,3x3)+z on MFMA (16->16 / 32->32 k3 s1, W,H % 16 == 0); AUTO
+#define PCC_IMPL_WINOGRAD 3 /* force Winograd F(2x2,3x3)+z on MFMA (Cin = Cout in {16,32,64}, k3 s1, W,H % 16 == 0); AUTO
                               picks it when eligible (env PCC_NO_WINOGRAD=1 disables)                */
 
 typedef struct {

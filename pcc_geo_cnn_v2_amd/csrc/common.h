@@ -52,4 +52,4 @@ bool pcc_wino_eligible(const pcc_conv_desc* d);
 int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed,
                   const float* bias, const float* residual, float* out, hipStream_t st);
 constexpr int PCC_WINO_U_FLOATS = 48 * 64 * 4;   // per (cin group, cout group): [z tap][point][lane][cin quad member]
-inline bool pcc_wino_channels(int cin, int cout) { return cin == cout && (cin == 16 || cin == 32); }
+inline bool pcc_wino_channels(int cin, int cout) { return cin == cout && (cin == 16 || cin == 32 || cin == 64); }

@@ -1342,11 +1342,12 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
         if (pcc_wino_channels(ci, co) && k == 3 && fs == 1) {
             static const bool no_wino = getenv("PCC_NO_WINOGRAD") != nullptr;
             static const bool no_wino32 = getenv("PCC_NO_WINOGRAD32") != nullptr;
-            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !no_wino && !(ci == 32 && (no_wino32 || d->D < 32)));
+            static const bool wino64 = getenv("PCC_NO_WINOGRAD64") == nullptr;
+            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !no_wino && !(ci == 32 && (no_wino32 || d->D < 32)) && !(ci == 64 && !wino64));
             if (want && pcc_wino_eligible(d)) return pcc_conv_wino(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, residual, out, st);
             PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD needs W and H multiples of 16");
         } else {
-            PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD covers 16->16 / 32->32 k3 stride-1 layers only");
+            PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD covers Cin = Cout in {16,32,64} k3 stride-1 layers only");
         }
         PCC_CASE_FWD(16, 16, 3, 1) PCC_CASE_FWD(32, 32, 3, 1) PCC_CASE_FWD(64, 64, 3, 1)
         PCC_CASE_FWD(16, 32, 3, 2) PCC_CASE_FWD(32, 64, 3, 2) PCC_CASE_FWD(64, 64, 3, 2)

@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 using namespace pccwino;
 
 bool pcc_wino_eligible(const pcc_conv_desc* d) {
-    if (d->Cin != d->Cout || (d->Cin != 16 && d->Cin != 32) || d->k != 3 || d->stride != 1) return false;
+    if (!pcc_wino_channels(d->Cin, d->Cout) || d->k != 3 || d->stride != 1) return false;
     if (d->W % 16 || d->H % 16) return false;
     const int ocs = d->out_cstride ? d->out_cstride : d->Cout;
     if (ocs % 4 || d->out_coffset % 4) return false;

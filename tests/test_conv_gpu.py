@@ -91,11 +91,11 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize('ch', [16, 32])
+@pytest.mark.parametrize('ch', [16, 32, 64])
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_winograd_conv_matches_oracle(ctx, oracle, case, ch):
     """conv_wino.hip: F(2x2,3x3) in x-y + direct z taps, same stated tolerance as the direct kernels.
-    32 -> 32 runs as 2 x 2 sub-convolutions of 16 channels with in-place partial sums."""
+    32 -> 32 / 64 -> 64 run as g x g sub-convolutions of 16 channels with in-place partial sums."""
     N, D, H, W, tr, bias, relu, res = case
     _run(ctx, oracle, N, D, H, W, ch, ch, 3, 1, tr, bias, relu, res, L.PCC_IMPL_WINOGRAD, seed=21)
 
