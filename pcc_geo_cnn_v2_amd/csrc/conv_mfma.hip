@@ -701,6 +701,210 @@ conv_tr2_kernel(ConvArgs a) {
 }
 
 // =====================================================================================================
+// transposed conv, stride 2, k = 3: channel-group pipelined variant (conv_tr2g_kernel).
+//   Same parity decomposition, but the loop nest is  cin group (16 ch) -> parity class -> tap:
+//   * one 16-channel group of the haloed input tile is staged at a time, global -> LDS directly
+//     (buffer_load ... lds: no staging registers, no ds_write, no per-item index math in the loop) into a double
+//     buffer; group g+1 is in flight while group g feeds the MFMAs;
+//   * the accumulators of ALL 8 parity classes stay live across the groups (8 x R x CTW float4);
+//   * the epilogue uses per-row offsets computed once and one buffer descriptor per parity class.
+// =====================================================================================================
+template <int CIN, int COUT, int TX, int TZ, int TY, int TXT, int R, int CTW>
+struct Tr2gCfg {
+    static constexpr int NG = CIN / 16, NCT = COUT / 16;
+    static constexpr int RY = 16 / TX;
+    static constexpr int NYB = TY / RY, NXB = TXT / TX;
+    static constexpr int NCG = NCT / CTW;
+    static constexpr int NW = TZ * (NYB / R) * NXB * NCG;
+    static constexpr int NT = NW * 64;
+    static constexpr int LZ = TZ + 1, LY = TY + 1, LX = TXT + 1;     // k3: taps reach b-1 only
+    static constexpr int VSQ = 5;                                     // 16-byte slots per voxel: 4 data + 1 pad (80 B stride)
+    static constexpr int VS = VSQ * 4;
+    static constexpr int NV = LZ * LY * LX;
+    static constexpr int CHUNKS = (NV * VSQ + 63) / 64;               // 1 KB wave-sized chunks of one group image
+    static constexpr int ITEMS = (CHUNKS + NW - 1) / NW;              // chunks per wave
+    static constexpr int BUF_BYTES = ITEMS * NW * 1024;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+};
+
+template <int CIN, int COUT, int TX, int TZ, int TY, int TXT, int R, int CTW>
+__global__ void __launch_bounds__((Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>::NT), 2)     // <= 256 registers: two waves per SIMD
+conv_tr2g_kernel(ConvArgs a, int ntiles) {
+    using C = Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>;
+    static_assert(C::NG % 2 == 0, "the LDS double buffer alternates per cin group across tiles");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int v = lane & 15, cq = lane >> 4;
+    const int G = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, G);
+    if (tile >= ntiles) return;
+
+    int wv = wave;
+    const int ct0 = (wv % C::NCG) * CTW; wv /= C::NCG;
+    const int w_xb = wv % C::NXB; wv /= C::NXB;
+    const int w_yg = wv % (C::NYB / R);
+    const int w_z = wv / (C::NYB / R);
+    const int ry = v / TX, rx = v % TX;
+    const int ly0 = w_yg * R * C::RY + ry, lx0 = w_xb * TX + rx;
+    // B operand base: voxel (w_z+1, ly0+1, lx0+1) of the haloed tile, channel quad cq
+    const int lane_off = (((w_z + 1) * C::LY + ly0 + 1) * C::LX + lx0 + 1) * C::VS + cq * 4;
+    constexpr int ROW_OFF = C::RY * C::LX * C::VS;
+
+    const unsigned dbg_nostore = (a.flags & 0x40000000) ? kOOB : 0u, dbg_nostage = (a.flags & 0x20000000) ? kOOB : 0u;   // profiling aids
+    // ---- staging items of this lane (fixed for the life of the workgroup): tile-local voxel and byte offset
+    unsigned relb[C::ITEMS];     // byte offset relative to the tile's (z-1, y-1, x-1) corner voxel, or OOB for pad slots
+    unsigned lzyx[C::ITEMS];     // lz | ly << 8 | lx << 16
+#pragma unroll
+    for (int it = 0; it < C::ITEMS; ++it) {
+        const int slot = (wave * C::ITEMS + it) * 64 + lane;
+        const int u = slot / C::VSQ, q = slot - u * C::VSQ;
+        const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
+        const int ly = rem / C::LX, lx = rem - ly * C::LX;
+        relb[it] = (u < C::NV && q < 4) ? (unsigned)((((lz * a.H + ly) * a.W + lx) * CIN + q * 4) * 4) : kOOB;
+        lzyx[it] = (unsigned)(lz | (ly << 8) | (lx << 16));
+    }
+    const unsigned in_bytes = (unsigned)a.D * a.H * a.W * CIN * 4u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // global -> LDS of cin group g of tile (n, bz0, by0, bx0); pure-VALU range test: a negative term sets the sign bit,
+    // and the sign bit IS the out-of-range offset (zeros land in LDS: SAME padding, tile overhang, pad slots)
+    auto stage_group = [&](int n_, int bz0, int by0, int bx0, int g, int buf) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.in + (size_t)n_ * a.D * a.H * a.W * CIN + g * 16, in_bytes - (unsigned)g * 64u);
+        const unsigned tbase = (unsigned)((((bz0 - 1) * a.H + (by0 - 1)) * a.W + (bx0 - 1)) * CIN * 4);
+#pragma unroll
+        for (int it = 0; it < C::ITEMS; ++it) {
+            const int gz = bz0 - 1 + (int)(lzyx[it] & 0xFF), gy = by0 - 1 + (int)((lzyx[it] >> 8) & 0xFF), gx = bx0 - 1 + (int)(lzyx[it] >> 16);
+            const unsigned neg = (unsigned)(gz | (a.D - 1 - gz) | gy | (a.H - 1 - gy) | gx | (a.W - 1 - gx)) & kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr)((char*)lds + buf * C::BUF_BYTES + (wave * C::ITEMS + it) * 1024), 16,
+                                                     (int)((tbase + relb[it]) | neg | dbg_nostage), 0, 0, 0);
+        }
+    };
+    auto decode = [&](int t, int& n_, int& bz0, int& by0, int& bx0) {
+        const int tx = t % a.ntx; t /= a.ntx;
+        const int ty = t % a.nty; t /= a.nty;
+        bz0 = (t % a.ntz) * TZ; by0 = ty * TY; bx0 = tx * TXT; n_ = t / a.ntz;
+    };
+
+    int n, bz0, by0, bx0;
+    decode(tile, n, bz0, by0, bx0);
+    stage_group(n, bz0, by0, bx0, 0, 0);
+
+    // weights packed in consumption order [g][class][tap in class][ct]
+    constexpr int NSEQ = 27;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(NSEQ * C::NG * C::NCT) * 1024u);
+    const unsigned wlane = lane * 16;
+    // vmcnt retires in order: a weight load issued AFTER the staging loads of the next group cannot be consumed before
+    // those have landed (HBM latency).  A deep ring (8 taps ahead = ~4500 cycles) keeps that wait out of the tap loop.
+    constexpr int RING = (CTW == 1) ? 9 : 3;
+    static_assert(NSEQ % RING == 0, "the weight ring position must repeat per group");
+    f32x4 wf[RING][CTW];
+    const size_t ovox_n = (size_t)a.OD * a.OH * a.OW;
+    const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
+    const float relu_lo = (a.flags & PCC_CONV_RELU) ? 0.f : -__builtin_inff();
+    const float clip_lo = (a.flags & PCC_CONV_CLIP01) ? 0.f : -__builtin_inff(), clip_hi = (a.flags & PCC_CONV_CLIP01) ? 1.f : __builtin_inff();
+    f32x4 bias4[CTW];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct)
+        bias4[ct] = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + (ct0 + ct) * 16 + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[8][R][CTW];
+#pragma unroll 1
+    for (;;) {
+        const int next = tile + G;
+        const bool has_next = next < ntiles;
+        int nn = n, nbz0 = bz0, nby0 = by0, nbx0 = bx0;
+        if (has_next) decode(next, nn, nbz0, nby0, nbx0);
+        // the weight stream restarts per tile
+#pragma unroll
+        for (int r = 0; r < RING - 1; ++r)
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct0 + ct) * 1024u);
+#pragma unroll 1
+        for (int g = 0; g < C::NG; ++g) {
+            // group g has landed in LDS (this wave's loads: vmcnt; the other waves': barrier); nobody reads the other buffer any more
+            __builtin_amdgcn_s_waitcnt(0x0F70 | ((RING - 1) * CTW));    // vmcnt(weights still in flight) expcnt(7) lgkmcnt(15)
+            __syncthreads();
+            if (g + 1 < C::NG) stage_group(n, bz0, by0, bx0, g + 1, (g + 1) & 1);
+            else if (has_next) stage_group(nn, nbz0, nby0, nbx0, 0, 0);          // next tile's first group under this tile's last
+            const float* lbase = lds + (g & 1) * (C::BUF_BYTES / 4) + lane_off;
+            const unsigned wg_off = (unsigned)(g * NSEQ * C::NCT) * 1024u;
+            int seq = 0;  // compile-time after unrolling
+#pragma unroll
+            for (int cls = 0; cls < 8; ++cls) {
+                const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+                bool first = true;      // first tap of the class: group 0 starts the accumulators from 0 (no zero-init pass)
+#pragma unroll
+                for (int kz = pz; kz < 3; kz += 2)
+#pragma unroll
+                    for (int ky = py; ky < 3; ky += 2)
+#pragma unroll
+                        for (int kx = px; kx < 3; kx += 2, ++seq) {
+                            const int dz = (pz - kz) / 2, dy = (py - ky) / 2, dx = (px - kx) / 2;      // 0 or -1
+                            const int toff = ((dz * C::LY + dy) * C::LX + dx) * C::VS;
+                            {   // weights two taps ahead (runs into the next group's first taps; past the end: zeros)
+#pragma unroll
+                                for (int ct = 0; ct < CTW; ++ct)
+                                    wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, wg_off + (unsigned)((seq + RING - 1) * C::NCT + ct0 + ct) * 1024u);
+                                PCC_PIN_VMEM();
+                            }
+                            f32x4 b[R];
+#pragma unroll
+                            for (int i = 0; i < R; ++i) b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
+                            if (first) {
+#pragma unroll
+                                for (int i = 0; i < R; ++i)
+#pragma unroll
+                                    for (int ct = 0; ct < CTW; ++ct)
+                                        if (g == 0) acc[cls][i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            first = false;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int i = 0; i < R; ++i)
+#pragma unroll
+                                    for (int ct = 0; ct < CTW; ++ct)
+                                        acc[cls][i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[cls][i][ct]);
+                        }
+            }
+        }
+
+        // ---- epilogue of this tile: per-row offsets, one descriptor per parity class
+        const int gzb = bz0 + w_z, gxb = bx0 + lx0;
+        unsigned ooff[R], roff[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int gyb = by0 + ly0 + i * C::RY;
+            const bool ok = gzb < a.D && gyb < a.H && gxb < a.W;
+            const unsigned vox = (unsigned)((2 * gzb * a.OH + 2 * gyb) * a.OW + 2 * gxb);
+            ooff[i] = ok ? (vox * (unsigned)a.ocs + (unsigned)a.oco + cq * 4) * 4u : kOOB;
+            roff[i] = ok ? (vox * (unsigned)COUT + cq * 4) * 4u : kOOB;
+        }
+#pragma unroll
+        for (int cls = 0; cls < 8; ++cls) {
+            const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+            const size_t cvox = ((size_t)pz * a.OH + py) * a.OW + px;
+            const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + ((size_t)n * ovox_n + cvox) * a.ocs, (unsigned)((ovox_n - cvox) * a.ocs * 4));
+            const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + ((size_t)n * ovox_n + cvox) * COUT : a.in, has_res ? (unsigned)((ovox_n - cvox) * COUT * 4) : 0u);
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    f32x4 o = acc[cls][i][ct] + bias4[ct];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], relu_lo);
+                    if (has_res) o += buf_load4(rres, roff[i], (unsigned)((ct0 + ct) * 64));      // (wave-uniform branch; no layer of the c* graphs takes it)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], clip_lo), clip_hi);
+                    // immediate soffset: the compiler guards the store-data hazard of this form (see conv_wino.hip)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)((ooff[i] + (unsigned)((ct0 + ct) * 64)) | dbg_nostore), 0, 0);
+                }
+        }
+        if (!has_next) break;
+        tile = next; n = nn; bz0 = nbz0; by0 = nby0; bx0 = nbx0;
+    }
+}
+
+// =====================================================================================================
 // forward conv with Cin = 1, stride 2 (first layer of every analysis transform).
 //   k-slots of each MFMA = 4 consecutive taps along x (x taps padded to a multiple of 4 with zero
 //   weights), so the B operand is one ds_read_b32 with an immediate offset.
@@ -1158,7 +1362,7 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
 }
 
 template <int CIN, int COUT, int KS>
-int launch_tr2(int tx, ConvArgs a, hipStream_t st) {
+int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
 #define PCC_TR2(TX, TZ, TY, TXT, R) PCC_TR2C(TX, TZ, TY, TXT, R, (COUT / 16))
 #define PCC_TR2C(TX, TZ, TY, TXT, R, CTW)                                                               \
     {                                                                                                   \
@@ -1167,14 +1371,28 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st) {
         return launch(conv_tr2_kernel<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,     \
                       a.N * a.ntz * a.nty * a.ntx, a, st);                                              \
     }
+#define PCC_TR2G(TX, TZ, TY, TXT, R, CTW)                                                               \
+    {                                                                                                   \
+        using C = Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>;                                          \
+        a.w += 27 * CIN * COUT;                                                                         \
+        a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
+        const int ntiles = a.N * a.ntz * a.nty * a.ntx;                                                 \
+        const int slots = num_cu * (C::NT > 256 ? 1 : 2);                                               \
+        return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,        \
+                      ntiles < slots ? ntiles : slots, a, st, ntiles);                                  \
+    }
+    static const bool tr2_old = getenv("PCC_TR2_OLD") != nullptr;
     if (tx == 16) {
+        if constexpr (KS == 3) { if (!tr2_old) { if constexpr (CIN >= 64) PCC_TR2G(16, 2, 4, 16, 2, 2) else PCC_TR2G(16, 2, 8, 16, 4, 1) } }
         if constexpr (CIN >= 64) PCC_TR2(16, 2, 4, 16, 2)
         else PCC_TR2(16, 2, 8, 16, 4)
     }
     if (tx == 8) {
+        if constexpr (KS == 3) { if (!tr2_old) { if constexpr (COUT >= 64) PCC_TR2G(8, 2, 4, 8, 1, 1) else PCC_TR2G(8, 2, 8, 8, 2, 1) } }
         if constexpr (COUT >= 64 && KS == 3) PCC_TR2C(8, 2, 4, 8, 1, 1)
         else PCC_TR2(8, 2, 8, 8, 2)
     }
+#undef PCC_TR2G
     if constexpr (COUT >= 32 && KS == 3) PCC_TR2C(4, 1, 4, 4, 1, 1)
     else PCC_TR2(4, 4, 4, 4, 1)
 #undef PCC_TR2
@@ -1193,9 +1411,9 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st) {
 #define PCC_FWD_ALL(X) PCC_FWD_P1(X) PCC_FWD_P2(X) PCC_FWD_P3(X) PCC_FWD_P4(X)
 #define PCC_TR2_ALL(X) PCC_TR2_P4(X) PCC_TR2_P5(X) PCC_TR2_P6(X)
 #define PCC_INST_FWD(CI, CO, K, S) template int launch_fwd<CI, CO, K, S>(int, ConvArgs, hipStream_t, int);
-#define PCC_INST_TR2(CI, CO, K) template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t);
+#define PCC_INST_TR2(CI, CO, K) template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t, int);
 #define PCC_EXT_FWD(CI, CO, K, S) extern template int launch_fwd<CI, CO, K, S>(int, ConvArgs, hipStream_t, int);
-#define PCC_EXT_TR2(CI, CO, K) extern template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t);
+#define PCC_EXT_TR2(CI, CO, K) extern template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t, int);
 #if PCC_PART == 0
 PCC_FWD_ALL(PCC_EXT_FWD)
 PCC_TR2_ALL(PCC_EXT_TR2)
@@ -1235,7 +1453,7 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
             if (pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && d->stride == 1)
                 return k3 * d->Cin * d->Cout + (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_U_FLOATS;
             return k3 * d->Cin * d->Cout;
-        case K_TR2: return k3 * d->Cin * d->Cout;
+        case K_TR2: return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1);     // k3: second copy in the order of conv_tr2g_kernel
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
         case K_COUT1: return k3 * d->Cin;
         case K_COUT1M: return 2 * 64 * 4;
@@ -1295,6 +1513,20 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                                 for (int j = 0; j < 4; ++j)
                                     pk[(((seq * NCT) + ct) * 64 + lane) * 4 + j] =
                                         Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
+        if (k == 3) {
+            // conv_tr2g_kernel: [g][parity class][taps of the class][ct][lane][j]
+            float* pg = pk + (size_t)27 * Cin * Cout;
+            for (int g = 0; g < NG; ++g) {
+                size_t sq = 0;
+                for (int pz = 0; pz < 2; ++pz) for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px)
+                    for (int kz = pz; kz < 3; kz += 2) for (int ky = py; ky < 3; ky += 2) for (int kx = px; kx < 3; kx += 2, ++sq)
+                        for (int ct = 0; ct < NCT; ++ct)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 4; ++j)
+                                    pg[((((size_t)g * 27 + sq) * NCT + ct) * 64 + lane) * 4 + j] =
+                                        Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
+            }
+        }
     } else if (p.kind == K_CIN1) {
         // [kz][ky][kxg][ct][lane] : kx = kxg*4 + (lane>>4) (zero beyond k), cout = ct*16 + (lane&15)
         const int KXG = (k + 3) / 4;
@@ -1336,7 +1568,7 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
     const int ci = d->Cin, co = d->Cout, k = d->k, s = d->stride;
 
 #define PCC_CASE_FWD(CI, CO, K, S) if (ci == CI && co == CO && k == K && fs == S) return launch_fwd<CI, CO, K, S>(p.tx, a, st, ctx->num_cu);
-#define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st);
+#define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st, ctx->num_cu);
     if (p.kind == K_FWD) {
         const int fs = p.flip ? 1 : s;
         if (pcc_wino_channels(ci, co) && k == 3 && fs == 1) {

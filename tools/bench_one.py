@@ -11,14 +11,15 @@ wshape = (k, k, k, cout, cin) if tr else (k, k, k, cin, cout)
 layer = ops.ConvLayer((rng.standard_normal(wshape) / np.sqrt(k ** 3 * cin)).astype(np.float32), rng.standard_normal(cout).astype(np.float32), s, bool(tr), True)
 x = torch.randn((B, D, D, D, cin), device=ctx.device)
 res = torch.randn(ops.conv_out_shape(layer, x.shape), device=ctx.device) if len(sys.argv) > 8 else None
-out = ops.conv3d(ctx, x, layer, residual=res, impl=IMPL)
+FL = int(os.environ.get('PCC_BENCH_FLAGS', '0'), 0)
+out = ops.conv3d(ctx, x, layer, residual=res, impl=IMPL, flags=FL)
 torch.cuda.synchronize()
 ts = []
 for rep in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        ops.conv3d(ctx, x, layer, residual=res, impl=IMPL, out=out)
+        ops.conv3d(ctx, x, layer, residual=res, impl=IMPL, out=out, flags=FL)
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 10)
 ms = min(ts)
