@@ -221,7 +221,15 @@ class CompressionModel:
         np.savez(os.path.join(checkpoint_dir, CHECKPOINT_FILE), **self.get_weights())
 
     def restore(self, checkpoint_dir):
+        """tf.train.Saver().restore(sess, tf.train.latest_checkpoint(dir)) (compress_octree.py:82,90-92): `model.npz`, or
+        -- when the directory holds the reference's own TF1 checkpoint -- its TensorBundle files (tf_checkpoint.py)."""
         path = os.path.join(checkpoint_dir, CHECKPOINT_FILE)
+        if not os.path.exists(path) and os.path.isdir(checkpoint_dir):
+            from . import tf_checkpoint
+            prefix = tf_checkpoint.latest_checkpoint(checkpoint_dir)
+            if prefix is not None and os.path.exists(prefix + '.index'):
+                tf_checkpoint.import_checkpoint(checkpoint_dir, self)
+                return
         assert os.path.exists(path), f'Checkpoint {checkpoint_dir} was not found'
         with np.load(path) as f:
             self.set_weights({k: f[k] for k in f.files})

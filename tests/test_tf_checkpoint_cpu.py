@@ -1,0 +1,109 @@
+"""TF1 checkpoint importer: TensorBundle reader against an independent writer, structural name
+mapping, `restore()` fallback.  Format parity is unpinned (no TensorFlow / no reference checkpoint in this environment)."""
+import os
+
+import numpy as np
+import pytest
+
+from pcc_geo_cnn_v2_amd import tf_checkpoint as T
+from pcc_geo_cnn_v2_amd.model_configs import ModelConfigType
+
+from tf_bundle_writer import write_bundle
+
+
+def test_crc32c_known_answers():
+    assert T.crc32c(b'123456789') == 0xE3069283              # the standard CRC-32C check value
+    assert T.crc32c(b'\x00' * 32) == 0x8A9136AA                # RFC 3720 B.4
+
+
+def test_bundle_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    v = {'a/kernel': rng.standard_normal((3, 3, 3, 2, 4)).astype(np.float32), 'a/bias': rng.standard_normal(4).astype(np.float32),
+         'global_step': np.array(1234, np.int64), 'tab': rng.integers(0, 65536, (7, 33)).astype(np.int32),
+         'a/kernel/Adam': np.zeros((3, 3, 3, 2, 4), np.float32), 'scalar_f': np.array(2.5, np.float32)}
+    for i in range(23):                                       # several data blocks, shared key prefixes
+        v[f'layer_with_a_long_shared_prefix/conv3d_{i}/bias'] = rng.standard_normal(i + 1).astype(np.float32)
+    prefix = str(tmp_path / 'model.ckpt-1234')
+    write_bundle(prefix, v, entries_per_block=4)
+    open(tmp_path / 'checkpoint', 'w').write('model_checkpoint_path: "model.ckpt-1234"\nall_model_checkpoint_paths: "model.ckpt-1234"\n')
+    assert T.latest_checkpoint(str(tmp_path)) == prefix
+    got = T.load_checkpoint(prefix, verify=True)
+    assert sorted(got) == sorted(v)
+    for k in v:
+        assert got[k].dtype == v[k].dtype and got[k].shape == v[k].shape and np.array_equal(got[k], v[k]), k
+    data = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    data[5] ^= 1
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(data))
+    with pytest.raises(AssertionError):
+        T.load_checkpoint(prefix, verify=True)
+
+
+def test_snappy_block():
+    raw = b'abcdabcdabcdabcd' + bytes(range(70)) + b'zzzzzzzzzzzzzzzzzzzz'
+    # literal(4) 'abcd', copy2(len 12, off 4), long literal(70), literal 'z', copy2(19, off 1); plus a copy1 element below
+    comp = bytes([len(raw)]) + bytes([3 << 2]) + b'abcd' + bytes([((12 - 1) << 2) | 2, 4, 0]) + \
+        bytes([60 << 2, 69]) + bytes(range(70)) + bytes([0 << 2]) + b'z' + bytes([((19 - 1) << 2) | 2, 1, 0])
+    assert T._snappy_decompress(comp) == raw
+    assert T._snappy_decompress(bytes([9]) + bytes([2 << 2]) + b'xyz' + bytes([((6 - 4) << 2) | 1, 3])) == b'xyzxyzxyz'
+
+
+def _tf_names(model):
+    """The reference's Keras auto-names under an arbitrary scoping: conv3d[_N] / conv3d_transpose[_N] in construction order
+    (analysis, synthesis, hyper_analysis, hyper_synthesis), plus Adam slots and the step counters a Saver also stores."""
+    w = model.get_weights()
+    out, nf, nt = {}, 0, 0
+    for prefix, transposed in (('analysis', False), ('synthesis', True), ('hyper_analysis', False), ('hyper_synthesis', True)):
+        idx = sorted({int(k.split('/')[1]) for k in w if k.startswith(prefix + '/')})
+        for i in idx:
+            n = nt if transposed else nf
+            leaf = ('conv3d_transpose' if transposed else 'conv3d') + (f'_{n}' if n else '')
+            scope = f'{prefix}_transform/block_{i // 3}/{leaf}'
+            for part in ('kernel', 'bias'):
+                if f'{prefix}/{i}/{part}' in w:
+                    out[f'{scope}/{part}'] = w[f'{prefix}/{i}/{part}']
+                    out[f'{scope}/{part}/Adam'] = np.zeros_like(w[f'{prefix}/{i}/{part}'])
+                    out[f'{scope}/{part}/Adam_1'] = np.zeros_like(w[f'{prefix}/{i}/{part}'])
+            if transposed:
+                nt += 1
+            else:
+                nf += 1
+    for k, val in w.items():
+        if k.startswith('entropy_bottleneck/') and not k.endswith('/offset'):
+            out[k] = val
+        if k.startswith('gaussian_conditional/') and not k.endswith('/offset'):
+            out[k] = val
+    out['global_step'] = np.array(77, np.int64)
+    out['beta1_power'] = np.array(0.9, np.float32)
+    out['beta2_power_1'] = np.array(0.999, np.float32)
+    return out
+
+
+@pytest.mark.parametrize('cfg', ['c1', 'c3p'])
+def test_import_into_model_and_restore_fallback(tmp_path, cfg):
+    src = ModelConfigType[cfg].build()
+    src.compress([1, 1, 16, 16, 16])
+    rng = np.random.default_rng(3)
+    w = src.get_weights()
+    for k in w:                                               # "trained" values
+        if k.split('/')[0] in ('analysis', 'synthesis', 'hyper_analysis', 'hyper_synthesis'):
+            w[k] = rng.standard_normal(w[k].shape).astype(np.float32)
+    w['entropy_bottleneck/quantiles'] = (w['entropy_bottleneck/quantiles'] * np.float32(0.37)).astype(np.float32)
+    src.set_weights({k: v for k, v in w.items() if not k.endswith(('quantized_cdf', 'cdf_length', 'offset'))})
+    ref = src.get_weights()
+    prefix = str(tmp_path / 'model.ckpt-77')
+    write_bundle(prefix, _tf_names(src), checksums=False)     # (pure-Python crc32c of ~8 MB is slow; covered by test_bundle_roundtrip)
+    open(tmp_path / 'checkpoint', 'w').write('model_checkpoint_path: "model.ckpt-77"\n')
+
+    dst = ModelConfigType[cfg].build()
+    dst.compress([1, 1, 16, 16, 16])
+    dst.restore(str(tmp_path))                               # no model.npz in there: TensorBundle fallback
+    got = dst.get_weights()
+    assert sorted(got) == sorted(ref)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+
+    # a checkpoint of another architecture is rejected with the offending key in the message
+    other = ModelConfigType['c1' if cfg != 'c1' else 'c3p'].build()
+    other.compress([1, 1, 16, 16, 16])
+    with pytest.raises(AssertionError):
+        T.import_checkpoint(str(tmp_path), other)
