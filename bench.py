@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--chunk', type=int, default=CHUNK)
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
+                    help="fp32 = the reference's arithmetic (the headline number); fp16 = fp16 MFMA / fp32 accumulate (BASELINE.json configs[4] flavour, informational)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -129,7 +131,7 @@ def main():
 
     # host range-coder threads: share the node's cores between the ranks
     coder_threads = max(8, (os.cpu_count() or 8) // max(world, 1))
-    model = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads)
+    model = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads, precision=args.precision)
     model.compress([1, 1, RES, RES, RES])
     w = synthetic_weights(model)
     model.set_weights(w)
@@ -200,7 +202,7 @@ def main():
         out = {
             'metric': 'voxel_blocks_64cubed_per_sec_encode_decode', 'value': value, 'unit': 'blocks/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'f16 operands / f32 accumulate (NOT the headline precision)', 'data': 'synthetic',
             'config': {'workload': 'c3p, lambda-independent graph, batch=32 synthetic 64^3 occupancy grids per GPU, '
                                    'fixed threshold idx 128, encode+decode (BASELINE.json configs[1])',
                        'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'coder_threads_per_rank': coder_threads, 'sharding': f'blocks x{world}',

@@ -57,6 +57,8 @@ int pcc_ctx_num_cu(pcc_ctx* ctx);
 #define PCC_CONV_RELU 2
 #define PCC_CONV_ADD 4     /* add `residual` AFTER the activation (ResidualLayer 'add' mode)      */
 #define PCC_CONV_CLIP01 8  /* np.clip(x_hat,0,1) fused (src/model_types.py:202), encoder flavour  */
+#define PCC_CONV_F16 16    /* fp16 matrix instructions (operands rounded RTN, fp32 accumulate and storage) on the
+                              direct MFMA kernels; BASELINE.json configs[4].  Not the default: the reference is fp32 */
 
 #define PCC_IMPL_AUTO 0    /* MFMA implicit-GEMM when the shape is covered, else generic          */
 #define PCC_IMPL_GENERIC 1 /* direct convolution, any shape (reference-order fp32 FMA chain)      */

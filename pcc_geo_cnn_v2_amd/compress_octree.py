@@ -84,7 +84,7 @@ def compress(args):
                 f'dense_tensor_shape {dense_tensor_shape} and {n_total} blocks')
 
     x_shape = np.concatenate(((1,), dense_tensor_shape))
-    model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size)
+    model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size, precision=args.precision)
     model.compress(x_shape)
     model.restore(args.checkpoint_dir)  # asserts 'Checkpoint ... was not found' like compress_octree.py:91
 
@@ -150,6 +150,9 @@ def build_parser():
     parser.add_argument('--data_format', default='channels_first', help='Data format used: channels_first or channels_last')
     parser.add_argument('--debug', default=False, action='store_true', help='Output debug data for point cloud.')
     parser.add_argument('--batch_size', type=int, default=32, help='Blocks resident on the GPU per pass (new).')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
+                        help='fp16: fp16 matrix instructions with fp32 accumulation on the conv layers (new; must match between '
+                             'compress and decompress).')
     return parser
 
 

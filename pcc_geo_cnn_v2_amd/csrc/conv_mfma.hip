@@ -38,6 +38,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// PCC_CONV_F16 (BASELINE.json configs[4]): the same fragments -- a lane's float4 holds k-slots 4*(lane>>4)..+3 of a
+// 16-channel group, exactly the k layout of v_mfma_f32_16x16x16_f16 -- are rounded to fp16 (v_cvt_pk_f16_f32, RTN) and
+// contracted by ONE matrix instruction instead of four; accumulation, bias, activations in HBM and LDS stay fp32.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16h(const f32x4& a, const f32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_convertvector(a, h16x4), __builtin_convertvector(b, h16x4), c, 0, 0, 0);
+}
 
 // Raw buffer resources: the hardware range check returns 0 for offsets >= num_records, which implements the
 // SAME zero padding (and the tile overhang) without a single branch; the descriptor is wave-uniform (SGPRs).
@@ -108,7 +115,7 @@ struct FwdCfg {
     static_assert(TY % RY == 0 && NYB % R == 0 && TXT % TX == 0, "bad tile");
 };
 
-template <int CIN, int COUT, int KS, int S, int TX, int TZ, int TY, int TXT, int R, int CTW = COUT / 16>
+template <int CIN, int COUT, int KS, int S, int TX, int TZ, int TY, int TXT, int R, int CTW = COUT / 16, bool F16 = false>
 __global__ void __launch_bounds__((FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW>::NT))
 conv_fwd_kernel(ConvArgs a) {
     using C = FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW>;
@@ -229,13 +236,20 @@ conv_fwd_kernel(ConvArgs a) {
                 }
                 // k-slot quarter j outermost: consecutive MFMAs go to different accumulators (the 40-cycle
                 // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                if constexpr (F16) {
 #pragma unroll
                     for (int i = 0; i < R; ++i)
 #pragma unroll
-                        for (int ct = 0; ct < CTW; ++ct)
-                            acc[i][ct] = mfma16(wf[ts % RING][ct][j], bb[ts & 1][i][j], acc[i][ct]);
+                        for (int ct = 0; ct < CTW; ++ct) acc[i][ct] = mfma16h(wf[ts % RING][ct], bb[ts & 1][i], acc[i][ct]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                            for (int ct = 0; ct < CTW; ++ct)
+                                acc[i][ct] = mfma16(wf[ts % RING][ct][j], bb[ts & 1][i][j], acc[i][ct]);
+                }
                 PCC_PIN_MEM_MFMA();
             }
             if (!last) {
@@ -295,13 +309,20 @@ conv_fwd_kernel(ConvArgs a) {
                     f32x4 b[R];
 #pragma unroll
                     for (int i = 0; i < R; ++i) b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    if constexpr (F16) {
 #pragma unroll
                         for (int i = 0; i < R; ++i)
 #pragma unroll
-                            for (int ct = 0; ct < CTW; ++ct)
-                                acc[i][ct] = mfma16(wf[ts % RING][ct][j], b[i][j], acc[i][ct]);
+                            for (int ct = 0; ct < CTW; ++ct) acc[i][ct] = mfma16h(wf[ts % RING][ct], b[i], acc[i][ct]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int i = 0; i < R; ++i)
+#pragma unroll
+                                for (int ct = 0; ct < CTW; ++ct)
+                                    acc[i][ct] = mfma16(wf[ts % RING][ct][j], b[i][j], acc[i][ct]);
+                    }
                 }
             }
         }
@@ -552,7 +573,7 @@ struct Tr2Cfg {
     static constexpr int ITEMS = (NV * Q + NT - 1) / NT;
 };
 
-template <int CIN, int COUT, int KS, int TX, int TZ, int TY, int TXT, int R, int CTW = COUT / 16>
+template <int CIN, int COUT, int KS, int TX, int TZ, int TY, int TXT, int R, int CTW = COUT / 16, bool F16 = false>
 __global__ void __launch_bounds__((Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>::NT))
 conv_tr2_kernel(ConvArgs a) {
     using C = Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>;
@@ -656,6 +677,12 @@ conv_tr2_kernel(ConvArgs a) {
 #pragma unroll
                                     for (int i = 0; i < R; ++i)
                                         b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF + g * 16);
+                                    if constexpr (F16) {
+#pragma unroll
+                                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                                            for (int ct = 0; ct < CTW; ++ct) acc[i][ct] = mfma16h(wf[seq % RING][ct], b[i], acc[i][ct]);
+                                    } else {
 #pragma unroll
                                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -663,6 +690,7 @@ conv_tr2_kernel(ConvArgs a) {
 #pragma unroll
                                             for (int ct = 0; ct < CTW; ++ct)
                                                 acc[i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[i][ct]);
+                                    }
                                 }
                             } else {
                                 const int seq0 = seq;
@@ -677,6 +705,12 @@ conv_tr2_kernel(ConvArgs a) {
 #pragma unroll
                                     for (int i = 0; i < R; ++i)
                                         b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF + g * 16);
+                                    if constexpr (F16) {
+#pragma unroll
+                                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                                            for (int ct = 0; ct < CTW; ++ct) acc[i][ct] = mfma16h(w1[ct], b[i], acc[i][ct]);
+                                    } else {
 #pragma unroll
                                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -684,6 +718,7 @@ conv_tr2_kernel(ConvArgs a) {
 #pragma unroll
                                             for (int ct = 0; ct < CTW; ++ct)
                                                 acc[i][ct] = mfma16(w1[ct][j], b[i][j], acc[i][ct]);
+                                    }
                                 }
                             }
                         }
@@ -727,7 +762,7 @@ struct Tr2gCfg {
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
 };
 
-template <int CIN, int COUT, int TX, int TZ, int TY, int TXT, int R, int CTW>
+template <int CIN, int COUT, int TX, int TZ, int TY, int TXT, int R, int CTW, bool F16 = false>
 __global__ void __launch_bounds__((Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>::NT), 2)     // <= 256 registers: two waves per SIMD
 conv_tr2g_kernel(ConvArgs a, int ntiles) {
     using C = Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>;
@@ -857,6 +892,12 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
                                         if (g == 0) acc[cls][i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             }
                             first = false;
+                            if constexpr (F16) {
+#pragma unroll
+                                for (int i = 0; i < R; ++i)
+#pragma unroll
+                                    for (int ct = 0; ct < CTW; ++ct) acc[cls][i][ct] = mfma16h(wf[seq % RING][ct], b[i], acc[cls][i][ct]);
+                            } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -864,6 +905,7 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
 #pragma unroll
                                     for (int ct = 0; ct < CTW; ++ct)
                                         acc[cls][i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[cls][i][ct]);
+                            }
                         }
             }
         }
@@ -1284,14 +1326,14 @@ static Plan make_plan(const pcc_conv_desc* d) {
 
 template <typename KernelT, typename... Extra>
 int launch(KernelT kern, int nt, int lds_bytes, int tiles, const ConvArgs& a, hipStream_t st, Extra... extra) {
-    static thread_local const void* configured[64];
+    static thread_local const void* configured[256];
     static thread_local int nconf = 0;
     bool done = false;
     for (int i = 0; i < nconf; ++i) done |= (configured[i] == (const void*)kern);
     if (!done) {
         if (lds_bytes > 64 * 1024)
             PCC_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        if (nconf < 64) configured[nconf++] = (const void*)kern;
+        if (nconf < 256) configured[nconf++] = (const void*)kern;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(nt), lds_bytes, st, a, extra...);
     PCC_CHECK_HIP(hipGetLastError());
@@ -1308,6 +1350,9 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
     {                                                                                                   \
         using C = FwdCfg<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW>;                                    \
         a.ntz = cdiv(a.OD, TZ); a.nty = cdiv(a.OH, TY); a.ntx = cdiv(a.OW, TXT);                        \
+        if (a.flags & PCC_CONV_F16)                                                                     \
+            return launch(conv_fwd_kernel<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW, true>, C::NT, C::LDS_BYTES, \
+                          a.N * a.ntz * a.nty * a.ntx, a, st);                                          \
         return launch(conv_fwd_kernel<CIN, COUT, KS, S, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,  \
                       a.N * a.ntz * a.nty * a.ntx, a, st);                                              \
     }
@@ -1323,7 +1368,7 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
                 if (big) PCC_FWD(16, 2, 8, 16, 4)
                 PCC_FWD(16, 2, 4, 16, 2)
             }
-            else if constexpr (COUT == 16 && CIN == 16 && KS == 3) {
+            else if (COUT == 16 && CIN == 16 && KS == 3 && !(a.flags & PCC_CONV_F16)) {
                 // persistent kernel, 2 workgroups per CU (tile 2x4x16, 80-byte LDS voxel stride)
 #define PCC_P16(TZ, TY, R, VS, WPC)                                                                     \
     {                                                                                                   \
@@ -1368,6 +1413,9 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
     {                                                                                                   \
         using C = Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>;                                       \
         a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
+        if (a.flags & PCC_CONV_F16)                                                                     \
+            return launch(conv_tr2_kernel<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW, true>, C::NT, C::LDS_BYTES, \
+                          a.N * a.ntz * a.nty * a.ntx, a, st);                                          \
         return launch(conv_tr2_kernel<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,     \
                       a.N * a.ntz * a.nty * a.ntx, a, st);                                              \
     }
@@ -1378,12 +1426,16 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
         a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
         const int ntiles = a.N * a.ntz * a.nty * a.ntx;                                                 \
         const int slots = num_cu * (C::NT > 256 ? 1 : 2);                                               \
+        if (a.flags & PCC_CONV_F16)                                                                     \
+            return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW, true>, C::NT, C::LDS_BYTES,  \
+                          ntiles < slots ? ntiles : slots, a, st, ntiles);                              \
         return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,        \
                       ntiles < slots ? ntiles : slots, a, st, ntiles);                                  \
     }
     static const bool tr2_old = getenv("PCC_TR2_OLD") != nullptr;
     if (tx == 16) {
-        if constexpr (KS == 3) { if (!tr2_old) { if constexpr (CIN >= 64) PCC_TR2G(16, 2, 4, 16, 2, 2) else PCC_TR2G(16, 2, 8, 16, 4, 1) } }
+        if constexpr (KS == 3) { if (!tr2_old) { static const int tv = getenv("PCC_TR2_VARIANT") ? atoi(getenv("PCC_TR2_VARIANT")) : 0;
+            if constexpr (CIN >= 64) { if (tv == 1) PCC_TR2G(16, 4, 4, 16, 2, 2) PCC_TR2G(16, 2, 4, 16, 2, 2) } else { if (tv == 1) PCC_TR2G(16, 4, 8, 16, 4, 1) if (tv == 2) PCC_TR2G(16, 2, 16, 16, 4, 1) PCC_TR2G(16, 2, 8, 16, 4, 1) } } }
         if constexpr (CIN >= 64) PCC_TR2(16, 2, 4, 16, 2)
         else PCC_TR2(16, 2, 8, 16, 4)
     }
@@ -1575,7 +1627,7 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
             static const bool no_wino = getenv("PCC_NO_WINOGRAD") != nullptr;
             static const bool no_wino32 = getenv("PCC_NO_WINOGRAD32") != nullptr;
             static const bool wino64 = getenv("PCC_NO_WINOGRAD64") == nullptr;
-            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !no_wino && !(ci == 32 && (no_wino32 || d->D < 32)) && !(ci == 64 && !wino64));
+            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !(d->flags & PCC_CONV_F16) && !no_wino && !(ci == 32 && (no_wino32 || d->D < 32)) && !(ci == 64 && !wino64));
             if (want && pcc_wino_eligible(d)) return pcc_conv_wino(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, residual, out, st);
             PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD needs W and H multiples of 16");
         } else {

@@ -47,7 +47,7 @@ def decompress(args):
     rank, world = sharding.world_info()
     sess = ops.get_context(torch.device('cuda', local_rank))
 
-    model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size)
+    model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size, precision=args.precision)
     compressed_data = []
     for file in args.input_files:
         with gzip.open(file, 'rb') as f:
@@ -97,6 +97,9 @@ def build_parser():
     parser.add_argument('--data_format', default='channels_first', help='Data format used: channels_first or channels_last')
     parser.add_argument('--debug', default=False, action='store_true', help='Use debug data to check results.')
     parser.add_argument('--batch_size', type=int, default=32, help='Blocks resident on the GPU per pass (new).')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
+                        help='fp16: fp16 matrix instructions with fp32 accumulation on the conv layers (new; must match between '
+                             'compress and decompress).')
     return parser
 
 

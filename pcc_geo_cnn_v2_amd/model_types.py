@@ -98,7 +98,9 @@ class _Pinned:
 
 class CompressionModel:
     def __init__(self, n_thresholds=2 ** 8, data_format='channels_first', batch_size=32,
-                 round_mode=L.PCC_ROUND_FLOOR_HALF, coder_threads=0, seed=42):
+                 round_mode=L.PCC_ROUND_FLOOR_HALF, coder_threads=0, seed=42, precision='fp32'):
+        assert precision in ('fp32', 'fp16'), "precision: 'fp32' (the reference's arithmetic) or 'fp16' (fp16 matrix instructions, fp32 accumulate)"
+        self.precision = precision
         self.thresholds = np.linspace(0, 1.0, n_thresholds)
         self.data_format = data_format
         self.batch_size = int(batch_size)
@@ -111,7 +113,11 @@ class CompressionModel:
 
     # ------------------------------------------------------------------ helpers
     def _ctx(self, sess):
-        return sess if isinstance(sess, ops.Context) else ops.get_context(None)
+        ctx = sess if isinstance(sess, ops.Context) else ops.get_context(None)
+        # BASELINE.json configs[4]: fp16 MFMA on the direct conv kernels.  Encoder and decoder must agree on it (the
+        # decoder recomputes sigma_hat): like the checkpoint, it is part of the codec configuration, not of the stream.
+        ctx.conv_flags = L.PCC_CONV_F16 if self.precision == 'fp16' else 0
+        return ctx
 
     def _dev(self, ctx, name, arr):
         key = (ctx.device.index, name)

@@ -127,6 +127,7 @@ def conv3d(ctx, x, layer, residual=None, flags=0, impl=L.PCC_IMPL_AUTO, out=None
     if residual is not None:
         flags |= L.PCC_CONV_ADD
         assert residual.is_contiguous() and tuple(residual.shape) == tuple(oshape)
+    flags |= getattr(ctx, 'conv_flags', 0)
     d = layer.desc(N, D, H, W, flags, impl, ocs, out_coffset)
     im = layer.device_images(ctx, d)
     prof = PROFILE is not None and PROFILE['match'](layer, x.shape)

@@ -173,3 +173,37 @@ def test_blocks_128_cubed_roundtrip_and_layer_parity(ctx, oracle):
     got = ops.conv3d(ctx, torch.from_numpy(t).to(ctx.device), heavy).cpu().numpy()
     ref = oracle.conv3d_transpose(t, heavy.kernel, heavy.bias, 1, True)
     assert np.abs(got - ref).max() <= 2e-5 * (1 + np.abs(ref).max())
+
+
+def test_config4_c6_128_cubed_fp16_mfma(ctx):
+    """BASELINE.json configs[4]: the deepest network (paper label c6 = the c3p graph), 128^3 blocks, batch 8, fp16 MFMA.
+    Size-independent properties: encode -> decode is bit-identical under the same precision (the decoder recomputes the same
+    sigma_hat / x_hat), the decoded point list is exactly np.argwhere, and the fp16 reconstruction stays within the stated
+    fp16 tolerance of the fp32 one when both decode the same symbols."""
+    res, B = 128, 8
+    enc = ModelConfigType['c3p'].build(batch_size=B, precision='fp16')
+    enc.compress([1, 1, res, res, res])
+    enc.set_weights(scaled_weights(enc, 2.2))
+    x = (torch.rand((B, res, res, res), generator=torch.Generator().manual_seed(11)) < 0.02).float().to(ctx.device)
+    e = enc._encode_batch(enc._ctx(ctx), x, debug=True)
+    strings = e['finish']()
+    dec = ModelConfigType['c3p'].build(batch_size=B, precision='fp16')
+    dec.decompress()
+    w_dec = {k: v for k, v in enc.get_weights().items() if not k.startswith(('analysis/', 'hyper_analysis/'))}
+    dec.set_weights(w_dec)
+    blocks, dbg = dec.decompress_blocks(ctx, [(s, 128) for s in strings], [res] * 3, debug=True)
+    thr = np.float32(np.linspace(0, 1, 256)[128])
+    for b in range(B):
+        assert np.array_equal(e['debug'][b]['x_hat'], dbg[b]['x_hat'])
+        assert np.array_equal(np.argwhere(dbg[b]['x_hat'][0, ..., 0] > thr).astype(np.float32), blocks[b])
+    # the same strings through the fp32 synthesis: hyper-synthesis runs in the decoder's own precision, so an fp32 decoder is
+    # NOT guaranteed to parse an fp16 stream (sigma_hat indexes may differ) -- compare the synthesis transform alone
+    y_hat = torch.from_numpy(np.stack([dbg[b]['y_hat'][0] for b in range(2)])).to(ctx.device)
+    c16 = enc._ctx(ctx)
+    xh16 = enc.synthesis_transform.forward_ndhwc(c16, y_hat).cpu().numpy()
+    ref = ModelConfigType['c3p'].build(batch_size=2)
+    ref.decompress()
+    ref.set_weights(w_dec)
+    xh32 = ref.synthesis_transform.forward_ndhwc(ref._ctx(ctx), y_hat).cpu().numpy()
+    assert not np.array_equal(xh16, xh32)
+    assert np.abs(xh16 - xh32).max() <= 2e-2 * (1 + np.abs(xh32).max())       # 10 chained layers at 4e-3 each, loosely

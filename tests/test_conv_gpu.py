@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-def _run(ctx, O, N, D, H, W, cin, cout, k, s, tr, bias, relu, res, impl, seed=0, clip=False):
+def _run(ctx, O, N, D, H, W, cin, cout, k, s, tr, bias, relu, res, impl, seed=0, clip=False, flags=0, tol=None):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((N, D, H, W, cin)).astype(np.float32)
     x[rng.random(x.shape) < 0.3] = 0
@@ -31,12 +31,12 @@ def _run(ctx, O, N, D, H, W, cin, cout, k, s, tr, bias, relu, res, impl, seed=0,
     rt = None if r is None else torch.from_numpy(r).to(ctx.device)
     if impl == L.PCC_IMPL_MFMA and not ops.mfma_supported(layer, x.shape):
         pytest.fail(f'MFMA path does not cover cin={cin} cout={cout} k={k} s={s} tr={tr} dims={(D, H, W)}')
-    out = ops.conv3d(ctx, xt, layer, residual=rt, impl=impl, flags=L.PCC_CONV_CLIP01 if clip else 0)
+    out = ops.conv3d(ctx, xt, layer, residual=rt, impl=impl, flags=(L.PCC_CONV_CLIP01 if clip else 0) | flags)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     assert got.shape == ref.shape
     err = np.abs(got - ref).max()
-    bound = TOL * (1 + np.abs(ref).max())
+    bound = (TOL if tol is None else tol) * (1 + np.abs(ref).max())
     assert err <= bound, f'max err {err} > {bound}; first bad {np.argwhere(np.abs(got - ref) > bound)[:5]}'
     return got
 
@@ -128,6 +128,20 @@ def test_winograd_concat_offset(ctx, oracle):
     got = out.cpu().numpy()
     assert np.abs(got[..., 12:28] - ref).max() < 1e-4
     assert np.all(got[..., :12] == 0) and np.all(got[..., 28:] == 0)
+
+
+# stated tolerance of the fp16-MFMA mode (BASELINE.json configs[4]): operands rounded to fp16 (2^-11 relative), fp32
+# accumulation over <= 27*64 products -> |err| <= 4e-3 * (1 + max|ref|) against the double-accumulation oracle
+TOL_F16 = 4e-3
+F16_CASES = [c for c in MFMA_CASES if c[4] % 16 == 0 and c[5] % 16 == 0]
+
+
+@pytest.mark.parametrize('case', F16_CASES)
+def test_fp16_mfma_conv_matches_oracle(ctx, oracle, case):
+    N, D, H, W, cin, cout, k, s, tr = case
+    got = _run(ctx, oracle, N, D, H, W, cin, cout, k, s, tr, True, True, True, L.PCC_IMPL_AUTO, seed=31, flags=L.PCC_CONV_F16, tol=TOL_F16)
+    ref32 = _run(ctx, oracle, N, D, H, W, cin, cout, k, s, tr, True, True, True, L.PCC_IMPL_MFMA, seed=31)
+    assert not np.array_equal(got, ref32), 'PCC_CONV_F16 did not select the fp16 kernels'
 
 
 def test_mfma_batch_partial_tiles_and_plain(ctx, oracle):
