@@ -835,7 +835,6 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
     const size_t ovox_n = (size_t)a.OD * a.OH * a.OW;
     const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
     const float relu_lo = (a.flags & PCC_CONV_RELU) ? 0.f : -__builtin_inff();
-    const float clip_lo = (a.flags & PCC_CONV_CLIP01) ? 0.f : -__builtin_inff(), clip_hi = (a.flags & PCC_CONV_CLIP01) ? 1.f : __builtin_inff();
     f32x4 bias4[CTW];
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct)
@@ -935,8 +934,10 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], relu_lo);
                     if (has_res) o += buf_load4(rres, roff[i], (unsigned)((ct0 + ct) * 64));      // (wave-uniform branch; no layer of the c* graphs takes it)
+                    if (a.flags & PCC_CONV_CLIP01) {                                                // (wave-uniform, ditto)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], clip_lo), clip_hi);
+                        for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
+                    }
                     // immediate soffset: the compiler guards the store-data hazard of this form (see conv_wino.hip)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)((ooff[i] + (unsigned)((ct0 + ct) * 64)) | dbg_nostore), 0, 0);
                 }
