@@ -762,8 +762,8 @@ struct Tr2gCfg {
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
 };
 
-template <int CIN, int COUT, int TX, int TZ, int TY, int TXT, int R, int CTW, bool F16 = false>
-__global__ void __launch_bounds__((Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>::NT), 2)     // <= 256 registers: two waves per SIMD
+template <int CIN, int COUT, int TX, int TZ, int TY, int TXT, int R, int CTW, bool F16 = false, int WPE = 2>
+__global__ void __launch_bounds__((Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>::NT), WPE)   // WPE waves per SIMD: <= 512 / WPE registers
 conv_tr2g_kernel(ConvArgs a, int ntiles) {
     using C = Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>;
     static_assert(C::NG % 2 == 0, "the LDS double buffer alternates per cin group across tiles");
@@ -786,6 +786,7 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
     constexpr int ROW_OFF = C::RY * C::LX * C::VS;
 
     const unsigned dbg_nostore = (a.flags & 0x40000000) ? kOOB : 0u, dbg_nostage = (a.flags & 0x20000000) ? kOOB : 0u;   // profiling aids
+    const bool dbg_noweights = (a.flags & 0x10000000) != 0;
     // ---- staging items of this lane (fixed for the life of the workgroup): tile-local voxel and byte offset
     unsigned relb[C::ITEMS];     // byte offset relative to the tile's (z-1, y-1, x-1) corner voxel, or OOB for pad slots
     unsigned lzyx[C::ITEMS];     // lz | ly << 8 | lx << 16
@@ -852,6 +853,18 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
         for (int r = 0; r < RING - 1; ++r)
 #pragma unroll
             for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct0 + ct) * 1024u);
+        // per-row output offsets of this tile (the epilogue of a parity class runs inside the last group, right after the
+        // class's taps: the 8 x R x CTW stores of a tile are spread over that group instead of bursting at its end)
+        const int gzb = bz0 + w_z, gxb = bx0 + lx0;
+        unsigned ooff[R], roff[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int gyb = by0 + ly0 + i * C::RY;
+            const bool ok = gzb < a.D && gyb < a.H && gxb < a.W;
+            const unsigned vox = (unsigned)((2 * gzb * a.OH + 2 * gyb) * a.OW + 2 * gxb);
+            ooff[i] = ok ? (vox * (unsigned)a.ocs + (unsigned)a.oco + cq * 4) * 4u : kOOB;
+            roff[i] = ok ? (vox * (unsigned)COUT + cq * 4) * 4u : kOOB;
+        }
 #pragma unroll 1
         for (int g = 0; g < C::NG; ++g) {
             // group g has landed in LDS (this wave's loads: vmcnt; the other waves': barrier); nobody reads the other buffer any more
@@ -874,7 +887,7 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
                         for (int kx = px; kx < 3; kx += 2, ++seq) {
                             const int dz = (pz - kz) / 2, dy = (py - ky) / 2, dx = (px - kx) / 2;      // 0 or -1
                             const int toff = ((dz * C::LY + dy) * C::LX + dx) * C::VS;
-                            {   // weights two taps ahead (runs into the next group's first taps; past the end: zeros)
+                            if (!dbg_noweights) {   // weights two taps ahead (runs into the next group's first taps; past the end: zeros)
 #pragma unroll
                                 for (int ct = 0; ct < CTW; ++ct)
                                     wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, wg_off + (unsigned)((seq + RING - 1) * C::NCT + ct0 + ct) * 1024u);
@@ -906,42 +919,29 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
                                         acc[cls][i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[cls][i][ct]);
                             }
                         }
+                if (g == C::NG - 1) {      // (wave-uniform) this class is complete: bias / ReLU / residual / clip, stores
+                const size_t cvox = ((size_t)pz * a.OH + py) * a.OW + px;
+                const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + ((size_t)n * ovox_n + cvox) * a.ocs, (unsigned)((ovox_n - cvox) * a.ocs * 4));
+                const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + ((size_t)n * ovox_n + cvox) * COUT : a.in, has_res ? (unsigned)((ovox_n - cvox) * COUT * 4) : 0u);
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        f32x4 o = acc[cls][i][ct] + bias4[ct];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], relu_lo);
+                        if (has_res) o += buf_load4(rres, roff[i], (unsigned)((ct0 + ct) * 64));      // (wave-uniform branch; no layer of the c* graphs takes it)
+                        if (a.flags & PCC_CONV_CLIP01) {                                                // (wave-uniform, ditto)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
+                        }
+                        // immediate soffset: the compiler guards the store-data hazard of this form (see conv_wino.hip)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)((ooff[i] + (unsigned)((ct0 + ct) * 64)) | dbg_nostore), 0, 0);
+                    }
+                }
             }
         }
 
-        // ---- epilogue of this tile: per-row offsets, one descriptor per parity class
-        const int gzb = bz0 + w_z, gxb = bx0 + lx0;
-        unsigned ooff[R], roff[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int gyb = by0 + ly0 + i * C::RY;
-            const bool ok = gzb < a.D && gyb < a.H && gxb < a.W;
-            const unsigned vox = (unsigned)((2 * gzb * a.OH + 2 * gyb) * a.OW + 2 * gxb);
-            ooff[i] = ok ? (vox * (unsigned)a.ocs + (unsigned)a.oco + cq * 4) * 4u : kOOB;
-            roff[i] = ok ? (vox * (unsigned)COUT + cq * 4) * 4u : kOOB;
-        }
-#pragma unroll
-        for (int cls = 0; cls < 8; ++cls) {
-            const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
-            const size_t cvox = ((size_t)pz * a.OH + py) * a.OW + px;
-            const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + ((size_t)n * ovox_n + cvox) * a.ocs, (unsigned)((ovox_n - cvox) * a.ocs * 4));
-            const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + ((size_t)n * ovox_n + cvox) * COUT : a.in, has_res ? (unsigned)((ovox_n - cvox) * COUT * 4) : 0u);
-#pragma unroll
-            for (int ct = 0; ct < CTW; ++ct)
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    f32x4 o = acc[cls][i][ct] + bias4[ct];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], relu_lo);
-                    if (has_res) o += buf_load4(rres, roff[i], (unsigned)((ct0 + ct) * 64));      // (wave-uniform branch; no layer of the c* graphs takes it)
-                    if (a.flags & PCC_CONV_CLIP01) {                                                // (wave-uniform, ditto)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
-                    }
-                    // immediate soffset: the compiler guards the store-data hazard of this form (see conv_wino.hip)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)((ooff[i] + (unsigned)((ct0 + ct) * 64)) | dbg_nostore), 0, 0);
-                }
-        }
         if (!has_next) break;
         tile = next; n = nn; bz0 = nbz0; by0 = nby0; bx0 = nbx0;
     }
@@ -1433,10 +1433,20 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
         return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,        \
                       ntiles < slots ? ntiles : slots, a, st, ntiles);                                  \
     }
+#define PCC_TR2G3(TX, TZ, TY, TXT, R, CTW)                                                              \
+    {                                                                                                   \
+        using C = Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>;                                          \
+        a.w += 27 * CIN * COUT;                                                                         \
+        a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
+        const int ntiles = a.N * a.ntz * a.nty * a.ntx;                                                 \
+        const int slots = num_cu * 3;                                                                   \
+        return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW, false, 3>, C::NT, C::LDS_BYTES, \
+                      ntiles < slots ? ntiles : slots, a, st, ntiles);                                  \
+    }
     static const bool tr2_old = getenv("PCC_TR2_OLD") != nullptr;
     if (tx == 16) {
         if constexpr (KS == 3) { if (!tr2_old) { static const int tv = getenv("PCC_TR2_VARIANT") ? atoi(getenv("PCC_TR2_VARIANT")) : 0;
-            if constexpr (CIN >= 64) { if (tv == 1) PCC_TR2G(16, 4, 4, 16, 2, 2) PCC_TR2G(16, 2, 4, 16, 2, 2) } else { if (tv == 1) PCC_TR2G(16, 4, 8, 16, 4, 1) if (tv == 2) PCC_TR2G(16, 2, 16, 16, 4, 1) PCC_TR2G(16, 2, 8, 16, 4, 1) } } }
+            if constexpr (CIN >= 64) { if (tv == 1) PCC_TR2G(16, 4, 4, 16, 2, 2) PCC_TR2G(16, 2, 4, 16, 2, 2) } else { if (tv == 1) PCC_TR2G(16, 4, 8, 16, 4, 1) if (tv == 2) PCC_TR2G(16, 2, 16, 16, 4, 1) if (tv == 3 && !(a.flags & PCC_CONV_F16)) PCC_TR2G3(16, 2, 4, 16, 2, 1) PCC_TR2G(16, 2, 8, 16, 4, 1) } } }
         if constexpr (CIN >= 64) PCC_TR2(16, 2, 4, 16, 2)
         else PCC_TR2(16, 2, 8, 16, 4)
     }
@@ -1446,6 +1456,7 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
         else PCC_TR2(8, 2, 8, 8, 2)
     }
 #undef PCC_TR2G
+#undef PCC_TR2G3
     if constexpr (COUT >= 32 && KS == 3) PCC_TR2C(4, 1, 4, 4, 1, 1)
     else PCC_TR2(4, 4, 4, 4, 1)
 #undef PCC_TR2
