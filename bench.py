@@ -97,7 +97,7 @@ def cpu_baseline(model, w, blocks_np, budget_s=12.0):
         T.codec_block_roundtrip(om, blocks_np[n % len(blocks_np)][None, ..., None])
         n += 1
         el = time.perf_counter() - t0
-        if (el > budget_s and n >= 2) or n >= 64:
+        if (el > budget_s and n >= 2) or n >= 1024:
             break
     return dict(value=n / el, unit='blocks/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'{n} c3p 64^3 blocks, batch 1 (model_types.py:192-198 loop), oracle/torch_oracle.py: '
