@@ -256,15 +256,16 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
                 for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i] + slotN);
             } else if (j == 2) transform_x_rows(Vn, 0, 2);
             else if (j == 3) transform_x_rows(Vn, 2, 4);
-            else if (j == 4) {
+            else if (j == 4 || j == 5) {
+                // residual (and partial sums of the previous cin groups, accumulated in place in `out`: same lane, same
+                // address) of the two voxels of output row oy = j - 4
 #pragma unroll
-                for (int q = 0; q < 4; ++q) resv[q] = buf_load4(rres, rvo[q], 0);
-                if (PRE) {   // partial sums of the previous cin groups, accumulated in place in `out` (same lane, same address)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) prev[q] = buf_load4(rout, ovo[q], 0);
+                for (int q = 2 * (j - 4); q < 2 * (j - 4) + 2; ++q) {
+                    resv[q] = buf_load4(rres, rvo[q], 0);
+                    if (PRE) prev[q] = buf_load4(rout, ovo[q], 0);
                 }
             }
-            else if (j >= 5 && j <= 8) {
+            if (j >= 5 && j <= 8) {
                 // A^T along x on row r of the finished plane, accumulate A^T along y
                 const int r = j - 5;
                 const f32x4 m0 = acc[AF][r * 4 + 0], m1 = acc[AF][r * 4 + 1], m2 = acc[AF][r * 4 + 2], m3 = acc[AF][r * 4 + 3];
@@ -273,11 +274,13 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
                 else if (r == 1) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = r0; S[1][1] = r1; }
                 else if (r == 2) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
                 else { S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
-            } else if (j == 9) {
-                // epilogue of the finished plane: bias, ReLU, residual, clip, float4 stores
+            }
+            if (j == 8 || j == 9) {
+                // epilogue of output row oy = j - 8 (complete after reduction row 2 resp. 3): ReLU, residual, clip, float4 stores
+                // (the bias is already inside, see the dz = 0 rows)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 o = S[q >> 1][q & 1];                  // (bias already inside, see the dz = 0 rows)
+                for (int q = 2 * (j - 8); q < 2 * (j - 8) + 2; ++q) {
+                    f32x4 o = S[q >> 1][q & 1];
                     if (PRE) o = add4(o, prev[q]);
                     if (RELU) {
 #pragma unroll
@@ -295,13 +298,15 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
                 // guards the immediate-soffset form with one wait state, so the data registers are kept live (and
                 // therefore unwritten) until the next slot.
 #pragma unroll
-                for (int q = 0; q < 4; ++q) buf_store4(rout, ost[q], ovo[q], 0);
-                transform_y_row(Vc, Vn, 0);
-            } else if (j == 10) {
+                for (int q = 2 * (j - 8); q < 2 * (j - 8) + 2; ++q) buf_store4(rout, ost[q], ovo[q], 0);
+            }
+            if (j == 9 || j == 10) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(ost[q]));
-                transform_y_row(Vc, Vn, 1);
-            } else if (j == 11) transform_y_row(Vc, Vn, 2);
+                for (int q = 2 * (j - 9); q < 2 * (j - 9) + 2; ++q) asm volatile("" ::"v"(ost[q]));
+            }
+            if (j == 9) transform_y_row(Vc, Vn, 0);
+            else if (j == 10) transform_y_row(Vc, Vn, 1);
+            else if (j == 11) transform_y_row(Vc, Vn, 2);
             __builtin_amdgcn_sched_barrier(0);
         }
         // The LDS-direct loads of plane s+2 (slot 1) must have landed before the barrier publishes them to the other
