@@ -1,7 +1,9 @@
 // Winograd F(2x2, 3x3) in (x, y) + direct 3 taps in z: 3-D convolution for gfx950 (CDNA4), fp32,
-// Cin = Cout = 16, k = 3, stride 1.
+// Cin = Cout in {16, 32, 64} (as g x g sub-convolutions of 16 channels), k = 3, stride 1 -- Conv3D and, through
+// host-flipped weights, Conv3DTranspose of /root/reference/src/model_transforms.py:62-70,93,107 (the k3 stride-1
+// layers of AnalysisBlock / SynthesisBlock and the last analysis conv).
 //
-// Why: the 16->16 k3 layers at 64^3 are bound by the fp32 MFMA rate (157 TFLOP/s).  The minimal-filtering form
+// Why: the k3 stride-1 layers are bound by the fp32 MFMA rate (157 TFLOP/s).  The minimal-filtering form
 // in the x-y plane needs 16 multiplies per 2x2 outputs, z tap and (cin, cout) pair instead of 36: 2.25x fewer
 // MFMAs, all still exact-fp32 v_mfma_f32_16x16x4_f32.  (The full 3-D form F(2^3,3^3) would save 3.375x but
 // needs > 256 VALU-visible registers per lane for the 4x4x4 patch pipeline; VALU cannot read AccVGPRs.)  The
