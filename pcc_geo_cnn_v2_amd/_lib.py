@@ -83,9 +83,7 @@ def lib():
     L.pcc_d1_search_workspace_bytes.restype = sz
     L.pcc_d1_threshold_stats.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ('pcc_abi_version',):
-            pass
+        getattr(L, name)          # AttributeError here = the shared object is older than the header
     _lib = L
     return L
 
