@@ -207,3 +207,52 @@ def test_config4_c6_128_cubed_fp16_mfma(ctx):
     xh32 = ref.synthesis_transform.forward_ndhwc(ref._ctx(ctx), y_hat).cpu().numpy()
     assert not np.array_equal(xh16, xh32)
     assert np.abs(xh16 - xh32).max() <= 2e-2 * (1 + np.abs(xh32).max())       # 10 chained layers at 4e-3 each, loosely
+
+
+def test_config2_cloud_1024_level4_sharded_equals_single(ctx):
+    """BASELINE.json configs[2] shape: a vox10-sized cloud (synthetic stand-in for longdress: a thin shell at 1024^3),
+    octree level 4 -> 64^3 blocks in Morton order, c3p.  (1) 8-way contiguous shards coded separately give bit-identical
+    strings / thresholds to the single pass, so rank 0 assembles the same file; (2) container -> decompress -> departition
+    returns exactly the encoder-side reconstruction."""
+    import gzip
+    import io
+    from pcc_geo_cnn_v2_amd import model_syntax, sharding
+    from pcc_geo_cnn_v2_amd.utils.octree_coding import departition_octree, partition_octree
+    R, level, res = 1024, 4, 64
+    # shell of radius 200 around (512, 500, 520): ~5e5 points in a few hundred 64^3 blocks, built without a 1024^3 grid
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal((3_000_000, 3))
+    pts = np.unique(np.round(u / np.linalg.norm(u, axis=1, keepdims=True) * 200 + np.array([512, 500, 520])).astype(np.int64), axis=0)
+    blocks, binstr = partition_octree(pts.astype(np.float64), [0, 0, 0], [R] * 3, level)
+    assert 150 < len(blocks) < 2000 and all(b.min() >= 0 and b.max() < res for b in blocks)
+    enc = ModelConfigType['c3p'].build(batch_size=32)
+    enc.compress([1, 1, res, res, res])
+    enc.set_weights(scaled_weights(enc, 2.2))
+    one = enc.encode_block_range(ctx, blocks, R, fixed_threshold=True)
+    strings, thr, cand = one[0], one[1], one[2]
+    sh_strings, sh_thr = [], []
+    for r in range(8):
+        lo, hi = sharding.shard_range(len(blocks), r, 8)
+        part = enc.encode_block_range(ctx, blocks[lo:hi], R, fixed_threshold=True)
+        sh_strings.extend(part[0])
+        sh_thr.extend(part[1])
+    assert sh_strings == strings and sh_thr == thr                     # batch / shard invariance: same bytes, same file
+    data = list(zip(strings, [t[0] for t in thr]))
+    raw = model_syntax.save_compressed_file(binstr, data, R, level, strict=True)
+    buf = io.BytesIO()
+    with gzip.open(buf, 'wb') as f:
+        f.write(raw)
+    buf.seek(0)
+    with gzip.open(buf, 'rb') as f:
+        r2, l2, binstr2, data2 = model_syntax.load_compressed_file(f)
+    assert (r2, l2) == (R, level) and list(binstr2) == list(binstr) and len(data2) == len(blocks)
+    dec = ModelConfigType['c3p'].build(batch_size=24)
+    dec.decompress()
+    dec.set_weights({k: v for k, v in enc.get_weights().items() if not k.startswith(('analysis/', 'hyper_analysis/'))})
+    dec_blocks, _ = dec.decompress_blocks(ctx, data2, [res] * 3)
+    for j in range(len(blocks)):
+        assert np.array_equal(dec_blocks[j], cand[j][0])              # decoder == encoder-side reconstruction, per block
+    cloud = departition_octree(dec_blocks, binstr2, [0, 0, 0], [R] * 3, level)
+    cloud = np.vstack(cloud) if isinstance(cloud, (list, tuple)) else cloud
+    assert len(cloud) == sum(len(b) for b in dec_blocks) and cloud.min() >= 0 and cloud.max() < R
+    print(f'cfg2 stand-in: {len(pts)} points, {len(blocks)} blocks, {len(raw)} container bytes, {len(cloud)} decoded points')
