@@ -180,6 +180,14 @@ int pcc_range_decode_batch(const pcc_cdf_table* t, int32_t n_streams, const uint
 /* tfc `pmf_to_quantized_cdf` (src/utils/patch_gaussian_conditional.py:87-89): pmf[n] -> cdf[n+1]. */
 int pcc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, int32_t* cdf);
 
+/* ---- octree blocking, host (replaces the per-point loop of src/utils/octree_coding.py:82-108) ----------------------
+ * Buckets `n` points (row-major doubles, `ncols` >= 3 columns, x y z first) into blocks of edge `block_size`:
+ * bucket = Morton code of the block id over `level` bits per axis, x least significant.  order[n] receives the point
+ * indices sorted by bucket, input order kept inside a bucket; bucket_count[8^level] the points per bucket.
+ * Returns the number of occupied buckets (>= 0) or a negative status.  level <= 7.                                   */
+int64_t pcc_octree_bucket(const double* points, int64_t n, int32_t ncols, int32_t block_size, int32_t level,
+                                     int64_t* order, int64_t* bucket_count);
+
 #ifdef __cplusplus
 }
 #endif

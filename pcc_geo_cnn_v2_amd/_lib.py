@@ -20,7 +20,7 @@ EXPORTS = [
     'pcc_conv3d', 'pcc_quantize', 'pcc_dequantize', 'pcc_scale_to_index', 'pcc_threshold_compact',
     'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
     'pcc_range_encode_batch', 'pcc_range_decode_batch', 'pcc_pmf_to_quantized_cdf',
-    'pcc_d1_search_workspace_bytes', 'pcc_d1_threshold_stats',
+    'pcc_d1_search_workspace_bytes', 'pcc_d1_threshold_stats', 'pcc_octree_bucket',
 ]
 
 
@@ -82,6 +82,8 @@ def lib():
     L.pcc_d1_search_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.pcc_d1_search_workspace_bytes.restype = sz
     L.pcc_d1_threshold_stats.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.pcc_octree_bucket.argtypes = [vp, C.c_int64, i32, i32, i32, vp, vp]
+    L.pcc_octree_bucket.restype = C.c_int64
     for name in EXPORTS:
         getattr(L, name)          # AttributeError here = the shared object is older than the header
     _lib = L

@@ -37,6 +37,36 @@ def _binstr_from_codes(codes, level):
     return [int(v) for v in nodes[order, 2]]
 
 
+def _partition_native(points, block_size, level):
+    """One counting sort in libpcc_geo_hip.so (csrc/octree.cpp, host code); None when the library is not built."""
+    try:
+        from .. import _lib as L
+        lib = L.lib()
+    except Exception:          # host-side helper: the numpy path below gives the same result
+        return None
+    n = len(points)
+    order = np.empty(n, np.int64)
+    counts = np.empty(8 ** level, np.int64)
+    occ = lib.pcc_octree_bucket(points.ctypes.data, n, points.shape[1], block_size, level, order.ctypes.data, counts.ctypes.data)
+    L.check(occ, 'pcc_octree_bucket')
+    codes = np.flatnonzero(counts)
+    ends = np.cumsum(counts[codes])
+    starts = ends - counts[codes]
+    # de-interleave the Morton codes of the occupied buckets back into block ids -> origins
+    c = codes.astype(np.uint64)
+    ids = np.zeros((len(codes), 3), np.int64)
+    for b in range(level):
+        for a in range(3):
+            ids[:, a] |= (((c >> np.uint64(3 * b + a)) & np.uint64(1)).astype(np.int64) << b)
+    sorted_pts = points[order]
+    blocks = []
+    for s_, e_, o in zip(starts, ends, ids * block_size):
+        blk = sorted_pts[s_:e_].copy()
+        blk[:, :3] -= o
+        blocks.append(blk)
+    return blocks, _binstr_from_codes(c, level)
+
+
 def partition_octree(points, bbox_min, bbox_max, level):
     points = np.asarray(points)
     if len(points) == 0 or level == 0:
@@ -47,6 +77,11 @@ def partition_octree(points, bbox_min, bbox_max, level):
     geo_level = int(np.ceil(np.log2(np.max(bbox_max))))
     assert geo_level >= level
     block_size = 2 ** (geo_level - level)
+
+    if level <= 7 and points.dtype == np.float64 and points.flags['C_CONTIGUOUS'] and (block_size << level) < 2 ** 31:
+        native = _partition_native(points, block_size, level)
+        if native is not None:
+            return native
 
     block_ids = (points[:, :3] // block_size).astype(np.uint32)
     # Morton key over the `level` bits of a block id.  The reference builds its key from
