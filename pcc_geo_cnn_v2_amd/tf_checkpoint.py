@@ -308,12 +308,16 @@ def convert_variables(variables, model):
         out['entropy_bottleneck/cdf_length'] = eb['cdf_length'].astype(np.int32)
         out['entropy_bottleneck/offset'] = (-minima).astype(np.int32)
     if 'quantized_cdf' in gc and 'gaussian_conditional/quantized_cdf' in want:
-        assert tuple(gc['quantized_cdf'].shape) == tuple(want['gaussian_conditional/quantized_cdf'].shape), \
-            (f'gaussian_conditional/quantized_cdf: checkpoint {gc["quantized_cdf"].shape} vs model '
-             f'{want["gaussian_conditional/quantized_cdf"].shape} (different tail_mass / scale table?)')
+        # Tables as stored (bit-exact rate).  Their width depends on the tail_mass the checkpoint was built with (tfc default
+        # 2**-8 -> 64 x 1481; 1e-9 -> 64 x 3133), so any width is accepted: a row holds pmf_length = 2*center + 1
+        # symbols plus the overflow bin, cdf_length = pmf_length + 2, and the offset is -center (patch_gaussian_conditional.py:63,96,118)
+        cl = gc['cdf_length'].astype(np.int32)
+        assert gc['quantized_cdf'].shape[0] == want['gaussian_conditional/quantized_cdf'].shape[0] == len(cl), \
+            f'gaussian_conditional: {gc["quantized_cdf"].shape[0]} table rows in the checkpoint, model has {want["gaussian_conditional/quantized_cdf"].shape[0]} scales'
+        assert np.all((cl - 3) % 2 == 0) and gc['quantized_cdf'].shape[1] >= int(cl.max()), 'gaussian_conditional: inconsistent cdf_length'
         out['gaussian_conditional/quantized_cdf'] = gc['quantized_cdf'].astype(np.int32)
-        out['gaussian_conditional/cdf_length'] = gc['cdf_length'].astype(np.int32)
-        out['gaussian_conditional/offset'] = want['gaussian_conditional/offset']          # symmetric table: a function of its width
+        out['gaussian_conditional/cdf_length'] = cl
+        out['gaussian_conditional/offset'] = (-((cl - 3) // 2)).astype(np.int32)
     return out, ignored
 
 

@@ -107,3 +107,22 @@ def test_import_into_model_and_restore_fallback(tmp_path, cfg):
     other.compress([1, 1, 16, 16, 16])
     with pytest.raises(AssertionError):
         T.import_checkpoint(str(tmp_path), other)
+
+
+def test_gaussian_tables_of_another_tail_mass_are_accepted(tmp_path):
+    """A checkpoint built with tail_mass = 1e-9 stores 64 x 3133 tables; the model default is 2**-8 (64 x 1481)."""
+    from pcc_geo_cnn_v2_amd.entropy_models import GaussianConditional
+    src = ModelConfigType['c3p'].build()
+    src.compress([1, 1, 16, 16, 16])
+    wide = GaussianConditional(src.conditional_bottleneck.scale_table, tail_mass=1e-9)
+    assert wide.quantized_cdf.shape == (64, 3133) and src.conditional_bottleneck.quantized_cdf.shape == (64, 1481)
+    v = _tf_names(src)
+    v['gaussian_conditional/quantized_cdf'], v['gaussian_conditional/cdf_length'] = wide.quantized_cdf, wide.cdf_length
+    prefix = str(tmp_path / 'model.ckpt-1')
+    write_bundle(prefix, v, checksums=False)
+    dst = ModelConfigType['c3p'].build()
+    dst.compress([1, 1, 16, 16, 16])
+    dst.restore(str(tmp_path))
+    gc = dst.conditional_bottleneck
+    assert np.array_equal(gc.quantized_cdf, wide.quantized_cdf) and np.array_equal(gc.cdf_length, wide.cdf_length)
+    assert np.array_equal(gc.offset, wide.offset)
