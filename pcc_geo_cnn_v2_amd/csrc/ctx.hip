@@ -2,6 +2,8 @@
 #include <cstring>
 #include <new>
 
+#include <cstdlib>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -76,6 +78,11 @@ PCC_API int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
     PCC_REQUIRE(!(d->flags & PCC_CONV_ADD) || residual, "pcc_conv3d: PCC_CONV_ADD set but residual is NULL");
     PCC_REQUIRE(d->out_cstride == 0 || d->out_cstride >= d->Cout + d->out_coffset,
                 "pcc_conv3d: out_cstride too small");
+    {   // bits 27..30 are profiling aids of conv_tr2g_kernel (skip stores / staging / weights): accepted only on request
+        static const bool prof = getenv("PCC_PROFILE_FLAGS") != nullptr;
+        const int32_t known = PCC_CONV_BIAS | PCC_CONV_RELU | PCC_CONV_ADD | PCC_CONV_CLIP01 | PCC_CONV_F16;
+        PCC_REQUIRE((d->flags & ~(known | (prof ? 0x78000000 : 0))) == 0, "pcc_conv3d: unknown bits in flags");
+    }
     PCC_CHECK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const bool fast_ok = w_packed != nullptr && pcc_conv_mfma_supported(d) == 1;

@@ -166,6 +166,15 @@ def test_mfma_is_bit_deterministic_and_batch_invariant(ctx):
     assert torch.equal(a[3:4], b)
 
 
+def test_unknown_flag_bits_are_rejected(ctx):
+    layer = ops.ConvLayer(np.zeros((3, 3, 3, 16, 16), np.float32), None, 1, False, False)
+    x = torch.zeros((1, 4, 16, 16, 16), device=ctx.device)
+    with pytest.raises(AssertionError):
+        ops.conv3d(ctx, x, layer, flags=0x40000000)      # a profiling bit without PCC_PROFILE_FLAGS
+    with pytest.raises(AssertionError):
+        ops.conv3d(ctx, x, layer, flags=1 << 9)
+
+
 def test_concat_mode_channel_offset(ctx, oracle):
     rng = np.random.default_rng(2)
     x = rng.standard_normal((1, 4, 4, 4, 2)).astype(np.float32)
