@@ -1233,14 +1233,13 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
         }
         // ---- (1) P = W x in for the haloed plane p
         f32x4 d0[C::PER_WAVE], d1[C::PER_WAVE];
-#pragma unroll
-        for (int k = 0; k < C::PER_WAVE; ++k) { d0[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; d1[k] = d0[k]; }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};      // first k-slot starts from the inline constant 0: no zero-init pass (VALU costs MFMA time)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < C::PER_WAVE; ++k) {
-                d0[k] = mfma16(wA0[j], cur[k][j], d0[k]);
-                d1[k] = mfma16(wA1[j], cur[k][j], d1[k]);
+                d0[k] = mfma16(wA0[j], cur[k][j], j == 0 ? zero4 : d0[k]);
+                d1[k] = mfma16(wA1[j], cur[k][j], j == 0 ? zero4 : d1[k]);
             }
 #pragma unroll
         for (int k = 0; k < C::PER_WAVE; ++k) {
