@@ -5,6 +5,7 @@ import numpy as np, torch
 from pcc_geo_cnn_v2_amd import ops, _lib as L
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+IMPL = int(os.environ.get("PCC_BENCH_IMPL", L.PCC_IMPL_AUTO))
 ctx = ops.Context(0)
 rng = np.random.default_rng(0)
 # (name, D, cin, cout, k, s, tr)
@@ -21,13 +22,13 @@ for name, D, cin, cout, k, s, tr in layers:
     w = (rng.standard_normal(wshape) / np.sqrt(k ** 3 * cin)).astype(np.float32)
     layer = ops.ConvLayer(w, rng.standard_normal(cout).astype(np.float32), s, bool(tr), True)
     x = torch.randn((B, D, D, D, cin), device=ctx.device)
-    out = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
+    out = ops.conv3d(ctx, x, layer, impl=IMPL)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 10
     e0.record()
     for _ in range(n):
-        ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA, out=out)
+        ops.conv3d(ctx, x, layer, impl=IMPL, out=out)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
