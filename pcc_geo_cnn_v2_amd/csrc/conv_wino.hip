@@ -95,6 +95,16 @@ __device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+// AccVGPR -> VGPR at a place of OUR choosing (the register allocator otherwise splits the live range right behind the
+// defining MFMA, i.e. in the middle of an MFMA block).  Inline asm is invisible to the hazard recogniser: callers keep at least
+// one slot of 16 MFMAs between the MFMA that wrote the accumulator and this read.
+__device__ __forceinline__ f32x4 acc_read(const f32x4& a) {
+    f32x4 d;
+    asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "a"(a[0]), "a"(a[1]), "a"(a[2]), "a"(a[3]));
+    return d;
+}
+
 // B^T along x, in place, on a 4x4 array of float4 (4 input channels each)
 __device__ __forceinline__ void transform_x_rows(f32x4 (&P)[16], int y0, int y1) {
 #pragma unroll
@@ -160,6 +170,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
         rel[it] = ok ? (unsigned)(((y * a.W + x) * a.ics + c4 * 4) * 4) : kOOB;   // OOB lanes write zeros (SAME padding / chunk padding)
     }
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    // (main loop) the plane addresses advance by one plane per step: 2 SALU adds instead of a 64-bit multiply per descriptor
+    unsigned long long in_pl = (unsigned long long)in_n + (unsigned long long)(long long)(zb + 1) * HWI;   // plane s+2 of step s = 0
     auto stage_plane = [&](unsigned plane_off, int z) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rp = plane_rsrc(z);
 #pragma unroll
@@ -218,17 +230,19 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }   // (planes finishing at s < 2 are never stored)
 
+    unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;     // plane zo of step s = 0
+    unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
     // one input plane: s = step index (input plane z = zb-1+s), PH = s mod 3
     auto step = [&](auto ph_tag, int s) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr unsigned slotN = (unsigned)((PH + 1) % 3) * PLANE_BYTES;   // plane s+1 (read)
         constexpr unsigned slotW = (unsigned)((PH + 2) % 3) * PLANE_BYTES;   // plane s+2 (written)
         constexpr int AF = PH;                                               // acc slot of the plane finished by dz = 2
-        const int zo = zb - 2 + s;                                           // that plane (valid when s >= 2)
-        const bool zo_ok = s >= 2;
+        const bool zo_ok = s >= 2;                                           // the finished plane zo = zb - 2 + s exists
         // plane-sized descriptors of the finished output plane; zero-sized (loads return 0, stores are dropped) while s < 2
-        const __amdgpu_buffer_rsrc_t rres = make_rsrc(res_n + (zo_ok && has_res ? (size_t)zo * HW * a.rcs : 0), zo_ok && has_res ? HWR : 0u);
-        const __amdgpu_buffer_rsrc_t rout = make_rsrc(out_n + (zo_ok ? (size_t)zo * HW * a.ocs : 0), zo_ok ? HWO : 0u);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res ? HWR : 0u);
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok ? HWO : 0u);
+        res_pl += HWR; out_pl += HWO;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int dz = 2 - (j >> 2), py = j & 3;
@@ -249,11 +263,22 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
                     const f32x4 c = (dz == 0 && kk == 0) ? ((py == 1 && px == 1) ? bias4 : zero4) : acc[as][py * 4 + px];
                     acc[as][py * 4 + px] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ub[j & 1][px][kk], Vc[py * 4 + px][kk], c, 0, 0, 0);
                 }
+            // An fp32 MFMA and a VALU op of the same wave share the SIMD's FMA lanes (tools/ubench/mfma_valu.hip): every
+            // MFMA -> VALU -> MFMA sandwich costs ~10 cycles of pipeline turn-around on top of ~3.7 cycles per VALU op, so
+            // the VALU work of a slot is issued as ONE block behind its 16 MFMAs instead of being interleaved with them.
+            __builtin_amdgcn_sched_barrier(0);
             // (3) everything else, spread over the slots.  Vc row r is last read by the MFMAs of slot 8+r, so the rows of
             //     the next plane are written in slots 9, 10, 11 and (row 3) slot 0 of the next step: no register copies.
             if (j == 0) transform_y_row(Vc, Vn, 3);
             else if (j == 1) {
-                stage_plane(slotW, zb - 1 + s + 2);
+                {
+                    const bool ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
+                    const __amdgpu_buffer_rsrc_t rp = make_rsrc((const void*)(ok ? in_pl : (unsigned long long)in_n), ok ? HWI : 0u);
+                    in_pl += HWI;
+#pragma unroll
+                    for (int it = 0; it < ITEMS; ++it)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + slotW + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i] + slotN);
             } else if (j == 2) transform_x_rows(Vn, 0, 2);
@@ -270,7 +295,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             if (j >= 5 && j <= 8) {
                 // A^T along x on row r of the finished plane, accumulate A^T along y
                 const int r = j - 5;
-                const f32x4 m0 = acc[AF][r * 4 + 0], m1 = acc[AF][r * 4 + 1], m2 = acc[AF][r * 4 + 2], m3 = acc[AF][r * 4 + 3];
+                const f32x4 m0 = acc_read(acc[AF][r * 4 + 0]), m1 = acc_read(acc[AF][r * 4 + 1]), m2 = acc_read(acc[AF][r * 4 + 2]), m3 = acc_read(acc[AF][r * 4 + 3]);
                 const f32x4 r0 = add4(add4(m0, m1), m2), r1 = sub4(sub4(m1, m2), m3);
                 if (r == 0) { S[0][0] = r0; S[0][1] = r1; }
                 else if (r == 1) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = r0; S[1][1] = r1; }

@@ -110,6 +110,7 @@ class CompressionModel:
         self.x_shape = None
         self._pinned = _Pinned()
         self._dev_cache = {}
+        self._host_cache = {}
 
     # ------------------------------------------------------------------ helpers
     def _ctx(self, sess):
@@ -152,6 +153,30 @@ class CompressionModel:
             done = torch.cuda.Event()
             done.record(self._copy_stream)
         return done
+
+    # ---- symbol order of the range-coded streams.  tfc 1.3 codes each batch item's tensor flattened in ITS memory order:
+    # with the reference's default data_format='channels_first' (model_types.py:180,254,377) that is (C,D,H,W), i.e.
+    # channel-major streams; 'channels_last' gives (D,H,W,C).  Internally everything is NDHWC, so for channels_first the
+    # int32 symbols / indexes are permuted on the GPU before they leave (and after they come back).
+    def _to_stream_order(self, t):
+        """(B,D,H,W,C) device tensor -> contiguous tensor in the stream's flattening order."""
+        return t.permute(0, 4, 1, 2, 3).contiguous() if self.data_format == 'channels_first' else t
+
+    def _from_stream_order(self, t):
+        """inverse of _to_stream_order: returns (B,D,H,W,C) contiguous."""
+        return t.permute(0, 2, 3, 4, 1).contiguous() if self.data_format == 'channels_first' else t
+
+    def _stream_shape(self, B, dhw, C):
+        return (B, C) + tuple(dhw) if self.data_format == 'channels_first' else (B,) + tuple(dhw) + (C,)
+
+    def _eb_rows(self, n_per_block, C):
+        """EntropyBottleneck CDF row (= channel) of every symbol of one stream: (index_list, index_mod) for the range coder."""
+        if self.data_format != 'channels_first':
+            return None, C                          # row = i % C
+        key = ('eb_rows', n_per_block, C)
+        if key not in self._host_cache:
+            self._host_cache[key] = np.repeat(np.arange(C, dtype=np.int32), n_per_block // C)
+        return self._host_cache[key], 0
 
     def _thr32(self, idx):
         # the reference compares float32 x_hat with a float64 scalar under numpy 1.18 value-based
@@ -459,32 +484,37 @@ class CompressionModelV1(CompressionModel):
         med = self._dev(ctx, 'medians', eb.medians)
         y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
         ysym, y_hat = ops.quantize(ctx, y, med, self.round_mode)
-        ysym_h = self._pinned.get('ysym', ysym.shape, torch.int32)
-        ev = self._copy_out(ctx, [(ysym_h, ysym)])
+        ysym_s = self._to_stream_order(ysym)
+        ysym_h = self._pinned.get('ysym', ysym_s.shape, torch.int32)
+        ev = self._copy_out(ctx, [(ysym_h, ysym_s)])
         x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+        rows, mod = self._eb_rows(ysym[0].numel(), self.num_filters)
 
         def finish():
             ev.synchronize()
-            ys = ops.range_encode_batch(eb.table, [ysym_h[b] for b in range(B)], None, self.num_filters, self.coder_threads)
+            ys = ops.range_encode_batch(eb.table, [ysym_h[b] for b in range(B)], None if rows is None else [rows] * B, mod,
+                                        self.coder_threads)
             return [(s,) for s in ys]
 
-        dbg = [{'y_hat': _np(y_hat[b:b + 1]), 'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))} for b in range(B)] if debug else [None] * B
+        dbg = [{'y': _np(y[b:b + 1]), 'symbols': _np(ysym[b:b + 1]), 'y_hat': _np(y_hat[b:b + 1]),
+                'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))} for b in range(B)] if debug else [None] * B
         return dict(x_hat=x_hat, finish=finish, debug=dbg)
 
     def _decode_phase_a(self, ctx, strings, dhw):
         B = len(strings)
         eb = self.entropy_bottleneck
-        yshape = (B, dhw[0] // 8, dhw[1] // 8, dhw[2] // 8, self.num_filters)
+        yshape = self._stream_shape(B, [v // 8 for v in dhw], self.num_filters)
         ysym_h = torch.empty(yshape, dtype=torch.int32, pin_memory=True)
         n = int(np.prod(yshape[1:]))
-        ops.range_decode_batch(eb.table, [s[0] for s in strings], [n] * B, None, self.num_filters, self.coder_threads,
-                               out=[ysym_h[b].numpy() for b in range(B)])
+        rows, mod = self._eb_rows(n, self.num_filters)
+        ops.range_decode_batch(eb.table, [s[0] for s in strings], [n] * B, None if rows is None else [rows] * B, mod,
+                               self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
         return dict(ysym_h=ysym_h)
 
     def _decode_phase_b(self, ctx, st, dhw, debug):
         eb = self.entropy_bottleneck
         med = self._dev(ctx, 'medians', eb.medians)
-        ysym = st['ysym_h'].to(ctx.device, non_blocking=True)
+        ysym = self._from_stream_order(st['ysym_h'].to(ctx.device, non_blocking=True))
         y_hat = ops.dequantize(ctx, ysym, med)
         x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
         B = x_hat.shape[0]
@@ -569,23 +599,27 @@ class CompressionModelV2(CompressionModel):
         sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
         idx = ops.scale_to_index(ctx, sigma, tab)
         ysym, y_hat = ops.quantize(ctx, y, None, self.round_mode)
-        zsym_h = self._pinned.get('zsym', zsym.shape, torch.int32)
-        ysym_h = self._pinned.get('ysym', ysym.shape, torch.int32)
-        idx_h = self._pinned.get('idx', idx.shape, torch.int32)
+        zsym_s, ysym_s, idx_s = self._to_stream_order(zsym), self._to_stream_order(ysym), self._to_stream_order(idx)
+        zsym_h = self._pinned.get('zsym', zsym_s.shape, torch.int32)
+        ysym_h = self._pinned.get('ysym', ysym_s.shape, torch.int32)
+        idx_h = self._pinned.get('idx', idx_s.shape, torch.int32)
         # symbols leave on a side stream so that the copies overlap the synthesis transform
-        ev = self._copy_out(ctx, [(zsym_h, zsym), (ysym_h, ysym), (idx_h, idx)])
+        ev = self._copy_out(ctx, [(zsym_h, zsym_s), (ysym_h, ysym_s), (idx_h, idx_s)])
         x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+        rows, mod = self._eb_rows(zsym[0].numel(), F)
 
         def finish():
             ev.synchronize()  # symbols are on the host; the synthesis transform is still running on the GPU
-            zs = ops.range_encode_batch(eb.table, [zsym_h[b] for b in range(B)], None, F, self.coder_threads)
+            zs = ops.range_encode_batch(eb.table, [zsym_h[b] for b in range(B)], None if rows is None else [rows] * B, mod,
+                                        self.coder_threads)
             ys = ops.range_encode_batch(gc.table, [ysym_h[b] for b in range(B)], [idx_h[b] for b in range(B)], 0,
                                         self.coder_threads)
             return list(zip(ys, zs))  # strings = (y_string, z_string), model_types.py:389
 
         dbg = [None] * B
         if debug:
-            dbg = [{'z_hat': _np(z_hat[b:b + 1]), 'sigma_hat': _np(sigma[b:b + 1]), 'indexes': _np(idx[b:b + 1]),
+            dbg = [{'y': _np(y[b:b + 1]), 'z': _np(z[b:b + 1]), 'z_symbols': _np(zsym[b:b + 1]),
+                    'z_hat': _np(z_hat[b:b + 1]), 'sigma_hat': _np(sigma[b:b + 1]), 'indexes': _np(idx[b:b + 1]),
                     'symbols': _np(ysym[b:b + 1]), 'y_hat': _np(y_hat[b:b + 1]), 'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))}
                    for b in range(B)]
         return dict(x_hat=x_hat, finish=finish, debug=dbg)
@@ -596,16 +630,18 @@ class CompressionModelV2(CompressionModel):
         eb, gc = self.entropy_bottleneck, self.conditional_bottleneck
         med = self._dev(ctx, 'medians', eb.medians)
         tab = self._dev(ctx, 'scale_table', gc.scale_table_f32)
-        zshape = (B, dhw[0] // 16, dhw[1] // 16, dhw[2] // 16, F)
+        zshape = self._stream_shape(B, [v // 16 for v in dhw], F)
         zsym_h = torch.empty(zshape, dtype=torch.int32, pin_memory=True)
         nz = int(np.prod(zshape[1:]))
-        ops.range_decode_batch(eb.table, [s[1] for s in strings], [nz] * B, None, F, self.coder_threads,
-                               out=[zsym_h[b].numpy() for b in range(B)])
-        z_hat = ops.dequantize(ctx, zsym_h.to(ctx.device, non_blocking=True), med)
+        rows, mod = self._eb_rows(nz, F)
+        ops.range_decode_batch(eb.table, [s[1] for s in strings], [nz] * B, None if rows is None else [rows] * B, mod,
+                               self.coder_threads, out=[zsym_h[b].numpy() for b in range(B)])
+        z_hat = ops.dequantize(ctx, self._from_stream_order(zsym_h.to(ctx.device, non_blocking=True)), med)
         sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
         idx = ops.scale_to_index(ctx, sigma, tab)
-        idx_h = torch.empty(idx.shape, dtype=torch.int32, pin_memory=True)
-        idx_h.copy_(idx, non_blocking=True)
+        idx_s = self._to_stream_order(idx)
+        idx_h = torch.empty(idx_s.shape, dtype=torch.int32, pin_memory=True)
+        idx_h.copy_(idx_s, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(ctx.device))
         return dict(strings=strings, idx_h=idx_h, ev=ev, z_hat=z_hat, sigma=sigma, idx=idx, zsym_h=zsym_h)
@@ -620,7 +656,7 @@ class CompressionModelV2(CompressionModel):
         n = int(np.prod(idx_h.shape[1:]))
         ops.range_decode_batch(gc.table, [s[0] for s in strings], [n] * B, [idx_h[b] for b in range(B)], 0,
                                self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
-        ysym = ysym_h.to(ctx.device, non_blocking=True)
+        ysym = self._from_stream_order(ysym_h.to(ctx.device, non_blocking=True))
         y_hat = ops.dequantize(ctx, ysym, None)
         x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
         dbg = [None] * B
