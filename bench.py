@@ -76,7 +76,7 @@ def cpu_baseline(model, w, blocks_np, budget_s=12.0):
     from oracle import oracle as O
     from oracle import torch_oracle as T
     eb, gc = model.entropy_bottleneck, model.conditional_bottleneck
-    om = dict(config='c3p', params=w, round_mode=0,
+    om = dict(config='c3p', params=w, round_mode=0, data_format=model.data_format,
               eb=dict(cdf=eb.quantized_cdf, cdf_size=eb.cdf_length, offset=eb.offset, medians=eb.medians),
               gc=(gc.quantized_cdf, gc.cdf_length, gc.offset), scale_table=gc.scale_table_f32)
     T.codec_block_roundtrip(om, blocks_np[0][None, ..., None])  # warm-up (oneDNN primitive creation)

@@ -339,58 +339,100 @@ def factorized_tables(eb, precision=16):
 # model = dict(config=<name>, params=<weights>, eb=<factorized_tables dict>, gc=(cdf,cdf_size,offset),
 #              scale_table=<float32 table>, round_mode=0|1)
 # ---------------------------------------------------------------------------------------------
-def compress_block(model, x):
-    """x: (1,D,H,W,1) float32 occupancy.  Returns (strings, x_hat (D,H,W) unclipped, debug)."""
+def to_stream(a, model):
+    """(1,D,H,W,C) tensor -> the flattening order of its range-coded stream.  tfc 1.3 codes a batch item's tensor in its
+    memory order: (C,D,H,W) under the reference's default data_format='channels_first' (model_types.py:180,254,377),
+    (D,H,W,C) under 'channels_last' (the default of this restatement)."""
+    a = np.asarray(a)
+    return np.ascontiguousarray(np.moveaxis(a, -1, 1)) if model.get('data_format') == 'channels_first' else a
+
+
+def from_stream(flat, shape_ndhwc, model):
+    """inverse of to_stream for a decoded flat symbol array."""
+    N, D, H, W, C = shape_ndhwc
+    if model.get('data_format') == 'channels_first':
+        return np.ascontiguousarray(np.moveaxis(np.reshape(flat, (N, C, D, H, W)), 1, -1))
+    return np.reshape(flat, shape_ndhwc)
+
+
+def _channel_rows(shape_ndhwc, model):
+    F = shape_ndhwc[-1]
+    return to_stream(np.broadcast_to(np.arange(F, dtype=np.int32), shape_ndhwc), model)
+
+
+def compress_block(model, x, run=None):
+    """x: (1,D,H,W,1) float32 occupancy.  Returns (strings, x_hat (D,H,W) unclipped, debug).
+    `run` replaces run_transform (e.g. torch_oracle.run_transform for 64^3 blocks)."""
+    run = run or run_transform
     cfg = CONFIGS[model['config']]
     P, F, rm = model['params'], cfg['F'], model.get('round_mode', 0)
     eb = model['eb']
-    y = run_transform(cfg['a'], F, P, 'analysis', x)
+    y = np.asarray(run(cfg['a'], F, P, 'analysis', x), np.float32)
     dbg = {'y': y}
     if cfg['v'] == 1:
-        ch = np.broadcast_to(np.arange(F, dtype=np.int32), y.shape)
         sym, y_hat = quantize(y, eb['medians'], rm)
-        y_string = range_encode(sym, ch, eb['cdf'], eb['cdf_size'], eb['offset'])
+        y_string = range_encode(to_stream(sym, model), _channel_rows(y.shape, model), eb['cdf'], eb['cdf_size'], eb['offset'])
         strings = (y_string,)
+        dbg.update(symbols=sym)
     else:
-        z = run_transform('HyperAnalysisTransform', F, P, 'hyper_analysis', y)
-        ch = np.broadcast_to(np.arange(F, dtype=np.int32), z.shape)
+        z = np.asarray(run('HyperAnalysisTransform', F, P, 'hyper_analysis', y), np.float32)
         zsym, z_hat = quantize(z, eb['medians'], rm)
-        z_string = range_encode(zsym, ch, eb['cdf'], eb['cdf_size'], eb['offset'])
-        sigma = run_transform('HyperSynthesisTransform', F, P, 'hyper_synthesis', z_hat)
+        z_string = range_encode(to_stream(zsym, model), _channel_rows(z.shape, model), eb['cdf'], eb['cdf_size'], eb['offset'])
+        sigma = np.asarray(run('HyperSynthesisTransform', F, P, 'hyper_synthesis', z_hat), np.float32)
         idx = scale_index(sigma, model['scale_table'])
         ysym, y_hat = quantize(y, None, rm)
         gcdf, gsize, goff = model['gc']
-        y_string = range_encode(ysym, idx, gcdf, gsize, goff)
+        y_string = range_encode(to_stream(ysym, model), to_stream(idx, model), gcdf, gsize, goff)
         strings = (y_string, z_string)
         dbg.update(z=z, z_hat=z_hat, sigma_hat=sigma, indexes=idx, symbols=ysym, z_symbols=zsym)
-    x_hat = run_transform(cfg['s'], F, P, 'synthesis', y_hat)
+    x_hat = np.asarray(run(cfg['s'], F, P, 'synthesis', y_hat), np.float32)
     dbg.update(y_hat=y_hat, x_hat=x_hat)
     return strings, x_hat[0, :, :, :, 0], dbg
 
 
-def decompress_block(model, strings, x_shape):
-    """x_shape: (D,H,W).  Returns x_hat (D,H,W) float32 (unclipped), debug."""
+def decompress_entropy_only(model, strings, x_shape, indexes):
+    """Range-decode the strings of one block with known indexes (no transforms): what the reference's compress graph does
+    with the strings it has just produced (model_types.py:292,383,387).  Returns the decoded symbol arrays (NDHWC)."""
+    cfg = CONFIGS[model['config']]
+    F, eb, xs = cfg['F'], model['eb'], np.asarray(x_shape)
+    if cfg['v'] == 1:
+        yshape = (1,) + tuple(xs // 8) + (F,)
+        return (from_stream(range_decode(strings[0], _channel_rows(yshape, model), eb['cdf'], eb['cdf_size'], eb['offset']), yshape, model),)
+    zshape, yshape = (1,) + tuple(xs // 16) + (F,), (1,) + tuple(xs // 8) + (F,)
+    zsym = from_stream(range_decode(strings[1], _channel_rows(zshape, model), eb['cdf'], eb['cdf_size'], eb['offset']), zshape, model)
+    gcdf, gsize, goff = model['gc']
+    idx = np.asarray(indexes, np.int32).reshape(yshape)
+    ysym = from_stream(range_decode(strings[0], to_stream(idx, model), gcdf, gsize, goff), yshape, model)
+    return ysym, zsym
+
+
+def decompress_block(model, strings, x_shape, run=None, indexes=None):
+    """x_shape: (D,H,W).  Returns x_hat (D,H,W) float32 (unclipped), debug.
+    `indexes` (NDHWC int32), when given, replaces the oracle's own scale indexes for the y stream: a decoder whose
+    sigma_hat differs in the last bit on a table boundary cannot parse the stream at all, so parity tests that compare
+    against an fp32-noise-different implementation hand over the encoder's indexes after checking them (tests/_stagecheck.py)."""
+    run = run or run_transform
     cfg = CONFIGS[model['config']]
     P, F = model['params'], cfg['F']
     eb = model['eb']
     xs = np.asarray(x_shape)
     if cfg['v'] == 1:
         yshape = (1,) + tuple(xs // 8) + (F,)
-        ch = np.broadcast_to(np.arange(F, dtype=np.int32), yshape)
-        sym = range_decode(strings[0], ch, eb['cdf'], eb['cdf_size'], eb['offset'])
+        sym = from_stream(range_decode(strings[0], _channel_rows(yshape, model), eb['cdf'], eb['cdf_size'], eb['offset']), yshape, model)
         y_hat = (sym.astype(np.float32) + eb['medians']).astype(np.float32)
-        dbg = {}
+        dbg = dict(symbols=sym)
     else:
         zshape = (1,) + tuple(xs // 16) + (F,)
-        ch = np.broadcast_to(np.arange(F, dtype=np.int32), zshape)
-        zsym = range_decode(strings[1], ch, eb['cdf'], eb['cdf_size'], eb['offset'])
+        yshape = (1,) + tuple(xs // 8) + (F,)
+        zsym = from_stream(range_decode(strings[1], _channel_rows(zshape, model), eb['cdf'], eb['cdf_size'], eb['offset']), zshape, model)
         z_hat = (zsym.astype(np.float32) + eb['medians']).astype(np.float32)
-        sigma = run_transform('HyperSynthesisTransform', F, P, 'hyper_synthesis', z_hat)
-        idx = scale_index(sigma, model['scale_table'])
+        sigma = np.asarray(run('HyperSynthesisTransform', F, P, 'hyper_synthesis', z_hat), np.float32)
+        own_idx = scale_index(sigma, model['scale_table'])
+        idx = own_idx if indexes is None else np.asarray(indexes, np.int32).reshape(yshape)
         gcdf, gsize, goff = model['gc']
-        ysym = range_decode(strings[0], idx, gcdf, gsize, goff)
+        ysym = from_stream(range_decode(strings[0], to_stream(idx, model), gcdf, gsize, goff), yshape, model)
         y_hat = ysym.astype(np.float32)
-        dbg = dict(z_hat=z_hat, sigma_hat=sigma, indexes=idx, symbols=ysym)
-    x_hat = run_transform(cfg['s'], F, P, 'synthesis', y_hat)
+        dbg = dict(z_symbols=zsym, z_hat=z_hat, sigma_hat=sigma, indexes=idx, own_indexes=own_idx, symbols=ysym)
+    x_hat = np.asarray(run(cfg['s'], F, P, 'synthesis', y_hat), np.float32)
     dbg.update(y_hat=y_hat, x_hat=x_hat)
     return x_hat[0, :, :, :, 0], dbg

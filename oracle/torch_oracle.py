@@ -61,7 +61,7 @@ def run_transform(name, filters, params, prefix, x):
         elif res == 'add':
             y = t1 + y
         x = y
-    return x
+    return x.numpy() if isinstance(x, torch.Tensor) else x
 
 
 def codec_block_roundtrip(model, x):
@@ -69,47 +69,14 @@ def codec_block_roundtrip(model, x):
     batch 1, exactly the unit of work of SURVEY.md §8d.  Conv stacks via oneDNN, entropy coding and
     thresholding via the C oracle.  Returns (strings, n_points_enc, n_points_dec)."""
     from . import oracle as O
-    cfg = O.CONFIGS[model['config']]
-    P, Fn, rm = model['params'], cfg['F'], model.get('round_mode', 0)
-    eb = model['eb']
     thr = np.float32(np.linspace(0, 1.0, 256)[128])
     with torch.no_grad():
-        # ---- compress graph (model_types.py:379-389 / :289-294)
-        y = run_transform(cfg['a'], Fn, P, 'analysis', x)
-        if cfg['v'] == 1:
-            ch = np.broadcast_to(np.arange(Fn, dtype=np.int32), tuple(y.shape))
-            sym, y_hat = O.quantize(y.numpy(), eb['medians'], rm)
-            strings = (O.range_encode(sym, ch, eb['cdf'], eb['cdf_size'], eb['offset']),)
-            _ = O.range_decode(strings[0], ch, eb['cdf'], eb['cdf_size'], eb['offset'])
-        else:
-            z = run_transform('HyperAnalysisTransform', Fn, P, 'hyper_analysis', y)
-            ch = np.broadcast_to(np.arange(Fn, dtype=np.int32), tuple(z.shape))
-            zsym, z_hat = O.quantize(z.numpy(), eb['medians'], rm)
-            z_string = O.range_encode(zsym, ch, eb['cdf'], eb['cdf_size'], eb['offset'])
-            _ = O.range_decode(z_string, ch, eb['cdf'], eb['cdf_size'], eb['offset'])
-            sigma = run_transform('HyperSynthesisTransform', Fn, P, 'hyper_synthesis', z_hat)
-            idx = O.scale_index(sigma.numpy(), model['scale_table'])
-            ysym, y_hat = O.quantize(y.numpy(), None, rm)
-            y_string = O.range_encode(ysym, idx, *model['gc'])
-            _ = O.range_decode(y_string, idx, *model['gc'])
-            strings = (y_string, z_string)
-        x_hat = run_transform(cfg['s'], Fn, P, 'synthesis', y_hat)[0, :, :, :, 0].numpy()
+        # ---- compress graph (model_types.py:379-389 / :289-294); the reference's encoder also range-DEcodes the strings
+        #      it has just written (:292, :383, :387) -- timed here as an extra decode of both streams
+        strings, x_hat, dbg = O.compress_block(model, x, run=run_transform)
+        O.decompress_entropy_only(model, strings, x.shape[1:4], dbg.get('indexes'))
         n_enc = len(O.threshold_argwhere(O.clip01(x_hat), thr))
         # ---- decompress graph (model_types.py:403-408 / :305-307)
-        xs = np.array(x.shape[1:4])
-        if cfg['v'] == 1:
-            yshape = (1,) + tuple(xs // 8) + (Fn,)
-            ch = np.broadcast_to(np.arange(Fn, dtype=np.int32), yshape)
-            sym = O.range_decode(strings[0], ch, eb['cdf'], eb['cdf_size'], eb['offset'])
-            y_hat = sym.astype(np.float32) + eb['medians']
-        else:
-            zshape = (1,) + tuple(xs // 16) + (Fn,)
-            ch = np.broadcast_to(np.arange(Fn, dtype=np.int32), zshape)
-            zsym = O.range_decode(strings[1], ch, eb['cdf'], eb['cdf_size'], eb['offset'])
-            z_hat = zsym.astype(np.float32) + eb['medians']
-            sigma = run_transform('HyperSynthesisTransform', Fn, P, 'hyper_synthesis', z_hat)
-            idx = O.scale_index(sigma.numpy(), model['scale_table'])
-            y_hat = O.range_decode(strings[0], idx, *model['gc']).astype(np.float32)
-        x_hat = run_transform(cfg['s'], Fn, P, 'synthesis', y_hat)[0, :, :, :, 0].numpy()
+        x_hat, _ = O.decompress_block(model, strings, x.shape[1:4], run=run_transform)
         n_dec = len(O.threshold_argwhere(x_hat, thr))
     return strings, n_enc, n_dec

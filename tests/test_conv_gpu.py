@@ -117,6 +117,35 @@ def test_winograd_is_deterministic_batch_invariant_and_close_to_direct(ctx):
         ops.conv3d(ctx, x[:, :, :8, :8].contiguous(), layer, impl=L.PCC_IMPL_WINOGRAD)   # H, W not multiples of 16
 
 
+@pytest.mark.parametrize('N,ch,D', [(8, 16, 64), (32, 16, 64), (8, 32, 32), (16, 64, 16)])
+def test_winograd_at_the_real_launch_geometry_matches_oracle(ctx, oracle, N, ch, D):
+    """The k3 stride-1 Conv3DTranspose layers of the c3p synthesis transform (/root/reference/src/model_transforms.py:78-80
+    through :126-137) at the launch geometry of bench.py -- 64^3 x 16 ch (the dominant layer; N = 32 is exactly the bench launch:
+    512 workgroups, 2 GiB of tensors), 32^3 x 32 ch, 16^3 x 64 ch -- bias + ReLU + residual, against the oneDNN restatement
+    oracle/torch_oracle.py (the naive C loops would need minutes), which the test first pins to the C oracle on a slab."""
+    from oracle import torch_oracle as T
+    rng = np.random.default_rng(33)
+    w = (rng.standard_normal((3, 3, 3, ch, ch)) / np.sqrt(27 * ch)).astype(np.float32)
+    b = rng.standard_normal(ch).astype(np.float32)
+    slab = rng.standard_normal((1, 3, 16, 16, ch)).astype(np.float32)
+    a, c = T.conv3d_transpose(slab, w, b, 1, True).numpy(), oracle.conv3d_transpose(slab, w, b, 1, True)
+    assert np.abs(a - c).max() <= 1e-5 * (1 + np.abs(c).max())          # the two restatements agree
+    layer = ops.ConvLayer(w, b, 1, True, True)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    worst = 0.0
+    x = torch.randn((N, D, D, D, ch), generator=g)
+    r = torch.randn((N, D, D, D, ch), generator=g)
+    got = ops.conv3d(ctx, x.to(ctx.device), layer, residual=r.to(ctx.device), impl=L.PCC_IMPL_WINOGRAD)
+    torch.cuda.synchronize()
+    got = got.cpu()
+    for n0 in range(0, N, 4):                      # the oracle in batches of 4 blocks (bounded host memory)
+        ref = T.conv3d_transpose(x[n0:n0 + 4], w, b, 1, True) + r[n0:n0 + 4]
+        err = (got[n0:n0 + 4] - ref).abs().max().item()
+        assert err <= TOL * (1 + ref.abs().max().item()), (n0, err)
+        worst = max(worst, err)
+    print(f'winograd {ch}ch @{D}^3 x{N}: max abs err {worst:.2e}')
+
+
 def test_winograd_concat_offset(ctx, oracle):
     rng = np.random.default_rng(4)
     x = rng.standard_normal((1, 4, 16, 16, 16)).astype(np.float32)

@@ -119,3 +119,36 @@ def test_oracle_block_roundtrip_small(oracle):
     x_dec, ddbg = oracle.decompress_block(om, strings, (16, 16, 16))
     assert np.array_equal(dbg['y_hat'], ddbg['y_hat']) and np.array_equal(x_hat, x_dec)
     assert len(strings) == 2 and x_hat.shape == (16, 16, 16)
+
+
+@pytest.mark.parametrize('name,data_format', [('c1', 'channels_first'), ('c3p', 'channels_first'), ('c3p', 'channels_last')])
+def test_stagecheck_accepts_an_independent_restatement(oracle, name, data_format):
+    """The staged parity checker used by the GPU tests (tests/_stagecheck.py), run on CPU: the oneDNN restatement plays the
+    part of the implementation under test and must pass every stage against the C loops -- and a corrupted string, a flipped
+    symbol or a wrong stream order must fail."""
+    import _stagecheck as SC
+    from oracle import torch_oracle as T
+    from pcc_geo_cnn_v2_amd.init_checkpoint import make_synthetic_weights
+    w = make_synthetic_weights(name, seed=3, gain_analysis=2.0, gain_synthesis=1.5)
+    om = dict(config=name, params=w, round_mode=0, data_format=data_format,
+              eb=dict(cdf=w['entropy_bottleneck/quantized_cdf'], cdf_size=w['entropy_bottleneck/cdf_length'],
+                      offset=w['entropy_bottleneck/offset'], medians=w['entropy_bottleneck/quantiles'][:, 0, 1]))
+    if name != 'c1':
+        om['scale_table'] = oracle.scale_table().astype(np.float32)
+        om['gc'] = (w['gaussian_conditional/quantized_cdf'], w['gaussian_conditional/cdf_length'], w['gaussian_conditional/offset'])
+    dense = (np.random.default_rng(1).random((16, 16, 16)) < 0.1).astype(np.float32)
+    strings, _, g = oracle.compress_block(om, dense[None, ..., None], run=T.run_transform)
+    info = SC.check_block(oracle, om, dense, g, strings)
+    assert info['sym_flips'] <= 4
+    bad = list(strings)
+    bad[0] = bad[0][:-1] + bytes([bad[0][-1] ^ 1])
+    with pytest.raises(AssertionError):
+        SC.check_block(oracle, om, dense, g, tuple(bad))
+    g2 = dict(g)
+    g2['symbols'] = g['symbols'].copy()
+    g2['symbols'].ravel()[5] += 1
+    with pytest.raises(AssertionError):
+        SC.check_block(oracle, om, dense, g2, strings)
+    other = dict(om, data_format='channels_last' if data_format == 'channels_first' else 'channels_first')
+    with pytest.raises(AssertionError):
+        SC.check_block(oracle, other, dense, g, strings)
