@@ -62,6 +62,7 @@ def compress(args):
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     rank, world = sharding.world_info()
+    assert not (args.debug and world > 1), '--debug dumps every intermediate of every block: run it on one GPU'
     sess = ops.get_context(torch.device('cuda', local_rank))  # replaces tf.Session (compress_octree.py:84)
 
     p_min, p_max, dense_tensor_shape = pc_io.get_shape_data(args.resolution, args.data_format)
@@ -98,10 +99,11 @@ def compress(args):
         data_list, data, debug_t_list = model.compress_blocks(sess, blocks, binstr, cur_points, args.resolution,
                                                               args.octree_level, with_normals=with_normals,
                                                               opt_metrics=args.opt_metrics, max_deltas=args.max_deltas,
-                                                              fixed_threshold=args.fixed_threshold, debug=args.debug)
-        assert len(data_list) == files_mult
+                                                              fixed_threshold=args.fixed_threshold, debug=args.debug,
+                                                              need_points=decode_files or args.debug)
         if rank != 0:
             continue
+        assert len(data_list) == files_mult
         for j in range(len(cur_output_files)):
             of, cur_data_list, cur_data = [x[j] for x in (cur_output_files, data_list, data)]
             if os.path.split(of)[0]:
@@ -139,7 +141,9 @@ def build_parser():
                         help='Decoded files. Allows compression/decompression in a single execution.')
     parser.add_argument('--checkpoint_dir', help='Directory where to save/load model checkpoints.', required=True)
     parser.add_argument('--model_config', help='Model used: c1, c2, c3, c3p.', required=True)
-    parser.add_argument('--opt_metrics', nargs='+', default=['d1_mse'],
+    # the reference's default 'd1_psnr' is not in avail_opt_metrics, so its CLI asserts unless --opt_metrics is given
+    # (compress_octree.py:156 + utils/pc_metric.py:62-66); kept for identical behaviour -- ev_experiment.py always passes it
+    parser.add_argument('--opt_metrics', nargs='+', default=['d1_psnr'],
                         help=f'Optimization metrics used. Available: {avail_opt_metrics}')
     parser.add_argument('--max_deltas', nargs='+', default=[np.inf], type=float, help='Max deltas tested during optimization.')
     parser.add_argument('--fixed_threshold', default=False, action='store_true', help='Enable fixed thresholding.')

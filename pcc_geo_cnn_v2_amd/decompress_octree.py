@@ -45,6 +45,7 @@ def decompress(args):
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     rank, world = sharding.world_info()
+    assert not (args.debug and world > 1), '--debug checks every intermediate of every block: run it on one GPU'
     sess = ops.get_context(torch.device('cuda', local_rank))
 
     model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size, precision=args.precision)

@@ -187,6 +187,9 @@ class CompressionModel:
         D, H, W = dhw
         B = len(blocks)
         pts = np.ascontiguousarray(np.concatenate([np.asarray(b)[:, :3] for b in blocks]).astype(np.uint32).astype(np.int32))
+        # the reference's dense scatter raises IndexError on an out-of-range coordinate (model_types.py:108-114)
+        assert pts.size == 0 or (pts.min() >= 0 and np.all(pts.max(0) < np.array(dhw))), \
+            f'block-local coordinates outside the {dhw} grid'
         bof = np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(blocks)])
         return ops.voxelize(ctx, torch.from_numpy(pts).to(ctx.device), torch.from_numpy(bof).to(ctx.device), B, D, H, W)
 
@@ -194,8 +197,12 @@ class CompressionModel:
         """x_hat (B,D,H,W) device; thr_idx list of ints -> list of (n,3) float32 numpy arrays."""
         # cached on the device: a pageable host->device copy here would block the host until the GPU drains
         # and serialise the pipeline
-        thr = self._dev(ctx, ('thr',) + tuple(int(t) for t in thr_idx),
-                        np.array([self._thr32(t) for t in thr_idx], np.float32))
+        thr_idx = [int(t) for t in thr_idx]
+        if len(set(thr_idx)) == 1:     # fixed threshold: one cached vector per (value, batch)
+            thr = self._dev(ctx, ('thr', thr_idx[0], len(thr_idx)), np.full(len(thr_idx), self._thr32(thr_idx[0]), np.float32))
+        else:                          # adaptive thresholds vary per chunk: gather from the cached 256-entry table
+            table = self._dev(ctx, 'thr_table', np.array([self._thr32(t) for t in range(len(self.thresholds))], np.float32))
+            thr = table[torch.tensor(thr_idx, dtype=torch.int64).to(ctx.device, non_blocking=True)]
         xyz, counts = ops.threshold_compact(ctx, x_hat, thr, clip=clip)
         return xyz, counts
 
@@ -294,7 +301,11 @@ class CompressionModel:
                 # adaptive search on the GPU: exact distance transforms instead of <= 255 KD-trees per block
                 opt_metrics_ret, best_all = compute_optimal_thresholds_gpu(ctx, chunk, x_hat, self.thresholds, resolution,
                                                                           opt_metrics, max_deltas)
-                n_m = len(best_all[0])
+                # a block whose decode is empty at every threshold returns len(opt_metrics) entries (model_opt.py:35-36); with
+                # more than one max_delta the reference's zip(*...) would silently drop the other candidates of the WHOLE
+                # cloud -- here the 'emit nothing' index is repeated instead
+                n_m = len(max_deltas) * len(opt_metrics)
+                best_all = [list(bt) + [bt[-1]] * (n_m - len(bt)) for bt in best_all]
                 per_metric = []
                 for m in range(n_m):
                     xyz, counts = self._extract_points(ctx, x_hat, [bt[m] for bt in best_all], clip=True)
@@ -311,6 +322,7 @@ class CompressionModel:
                     opt_metrics_ret, best = compute_optimal_thresholds(block, xh[j], self.thresholds, resolution,
                                                                        normals=normals, opt_metrics=opt_metrics,
                                                                        max_deltas=max_deltas, fixed_threshold=False)
+                    best = list(best) + [best[-1]] * (len(max_deltas) * len(opt_metrics) - len(best))     # see above
                     threshold_list.append(best)
                     x_hat_list.append([np.argwhere(xh[j] > self._thr32(t)).astype(np.float32) for t in best])
             strings_list.extend(strings)
@@ -318,26 +330,91 @@ class CompressionModel:
         return strings_list, threshold_list, x_hat_list, opt_metrics_ret, debug_t_list
 
     def compress_blocks(self, sess, blocks, binstr, points, resolution, level, with_normals=False,
-                        opt_metrics=('d1_mse',), max_deltas=(np.inf,), fixed_threshold=False, debug=False):
-        """Uses the compression model to compress a point cloud (model_types.py:184-218).  Under
-        torch.distributed (one process per GPU) the block list is sharded and gathered (sharding.py)."""
+                        opt_metrics=('d1_mse',), max_deltas=(np.inf,), fixed_threshold=False, debug=False,
+                        need_points=True):
+        """Uses the compression model to compress a point cloud (model_types.py:184-218).  Under torch.distributed (one
+        process per GPU) the block list is sharded (sharding.py): rank 0 returns the complete result, the other ranks
+        return (None, metadata without point lists, local debug list).  `need_points=False` skips the gather of the
+        decoded candidate point lists to rank 0 (they are only needed for --dec_files / --debug)."""
         from . import sharding
         rank, world = sharding.world_info()
+        if world == 1:
+            strings_list, threshold_list, x_hat_list, opt_metrics_ret, debug_t_list = self.encode_block_range(
+                sess, blocks, resolution, with_normals, opt_metrics, max_deltas, fixed_threshold, debug)
+            # block -> opt metric to opt metric -> block
+            threshold_list = list(zip(*threshold_list))
+            x_hat_list = list(zip(*x_hat_list))
+            metadata = select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics_ret, points, resolution, with_normals)
+            data_list = [list(zip(strings_list, threshold_list[x['idx']])) for x in metadata]
+            return data_list, metadata, debug_t_list
+        return self._compress_blocks_sharded(sess, blocks, binstr, points, resolution, level, with_normals, opt_metrics,
+                                             max_deltas, fixed_threshold, debug, need_points)
+
+    def _compress_blocks_sharded(self, sess, blocks, binstr, points, resolution, level, with_normals, opt_metrics,
+                                 max_deltas, fixed_threshold, debug, need_points):
+        from . import sharding
+        from .utils.octree_coding import block_origins
+        rank, world = sharding.world_info()
         lo, hi = sharding.shard_range(len(blocks), rank, world)
-        local = self.encode_block_range(sess, blocks[lo:hi], resolution, with_normals, opt_metrics, max_deltas,
-                                        fixed_threshold, debug)
-        strings_list, threshold_list, x_hat_list, debug_t_list, opt_metrics_ret = [], [], [], [], None
-        for s, t, x, names, dbg in sharding.gather_objects(local):
-            strings_list.extend(s)
-            threshold_list.extend(t)
-            x_hat_list.extend(x)
-            debug_t_list.extend(dbg)
-            opt_metrics_ret = opt_metrics_ret or names
-        # block -> opt metric to opt metric -> block
-        threshold_list = list(zip(*threshold_list))
-        x_hat_list = list(zip(*x_hat_list))
-        metadata = select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics_ret, points, resolution, with_normals)
-        data_list = [list(zip(strings_list, threshold_list[x['idx']])) for x in metadata]
+        strings_l, thr_l, xhat_l, names, debug_t_list = self.encode_block_range(
+            sess, blocks[lo:hi], resolution, with_normals, opt_metrics, max_deltas, fixed_threshold, debug)
+        n_str = 1 if isinstance(self, CompressionModelV1) else 2
+        n_m = len(max_deltas) * len(opt_metrics)
+        if names is None or not len(blocks[lo:hi]):
+            names = [f'{m}_{d}' for d in max_deltas for m in opt_metrics]
+        # (1) one int64 row per block: string lengths, threshold index and candidate point count per metric
+        rows = np.zeros((hi - lo, n_str + 2 * n_m), np.int64)
+        for j in range(hi - lo):
+            rows[j, :n_str] = [len(x) for x in strings_l[j]]
+            rows[j, n_str:n_str + n_m] = thr_l[j][:n_m]
+            rows[j, n_str + n_m:] = [len(x) for x in xhat_l[j][:n_m]]
+        table = sharding.all_gather_rows(rows)
+        assert table.shape[0] == len(blocks)
+        # (2) the strings: one padded uint8 gather to rank 0
+        blobs = sharding.gather_bytes(b''.join(x for ss in strings_l for x in ss))
+        # (3) D1/D2 of every candidate from per-rank partial sums; the selection is replicated (all_reduce)
+        origins = block_origins(binstr, [0, 0, 0], [resolution] * 3, level)[lo:hi]
+        p1, p1_n = points[:, :3], get_normals_if(points, with_normals)
+        t1 = cKDTree(p1)
+        cand_global = []
+        for m in range(n_m):
+            parts = [np.asarray(xhat_l[j][m], np.float64).reshape(-1, 3) + np.asarray(origins[j], np.float64) for j in range(hi - lo)]
+            cand_global.append(np.vstack(parts) if parts else np.zeros((0, 3)))
+        cand_metrics = [sharding.sharded_metrics(p1, cand_global[m], resolution - 1, p1_n, t1) for m in range(n_m)]
+        metadata = []
+        for group in ('d1', 'd2'):
+            idxs = [i for i, nm in enumerate(names) if nm.startswith(group)]
+            if not idxs:
+                continue
+            key = f'{group}_psnr'
+            cur = [cand_metrics[i] if cand_metrics[i] is not None else {key: -np.inf} for i in idxs]
+            best = idxs[int(np.argmax([c[key] for c in cur]))]
+            metadata.append({'idx': best, 'metrics': cand_metrics[best] if cand_metrics[best] is not None else {key: -np.inf}})
+            logger.info(f'Group {group} : {key} best idx {best} {names[best]}\n' +
+                        pprint.pformat({names[i]: f"{c[key]:.2f}" for i, c in zip(idxs, cur)}))
+        # (4) the reconstruction of the selected candidates on rank 0 (only for --dec_files / --debug)
+        if need_points:
+            for md in metadata:
+                m = md['idx']
+                flat = sharding.gather_rows(np.vstack([np.asarray(xhat_l[j][m], np.float32).reshape(-1, 3) for j in range(hi - lo)])
+                                            if hi > lo else np.zeros((0, 3), np.float32))
+                if rank == 0:
+                    off = np.concatenate([[0], np.cumsum(table[:, n_str + n_m + m])])
+                    md['x_hat_list'] = tuple(flat[off[j]:off[j + 1]] for j in range(len(blocks)))
+                    md['blocks_depart'] = departition_octree(md['x_hat_list'], binstr, [0, 0, 0], [resolution] * 3, level)
+                    md['blocks_full'] = np.vstack(md['blocks_depart'])
+        if rank != 0:
+            return None, metadata, debug_t_list
+        # rank 0: split the gathered strings back into per-block tuples, block order == rank order
+        strings_list, raw, pos = [], b''.join(blobs), 0
+        for j in range(len(blocks)):
+            ss = []
+            for k in range(n_str):
+                ss.append(raw[pos:pos + int(table[j, k])])
+                pos += int(table[j, k])
+            strings_list.append(tuple(ss))
+        assert pos == len(raw)
+        data_list = [list(zip(strings_list, [int(t) for t in table[:, n_str + md['idx']]])) for md in metadata]
         return data_list, metadata, debug_t_list
 
     def roundtrip_stream(self, sess, dense_chunks, thr_idx=None, gather=True):
@@ -394,14 +471,20 @@ class CompressionModel:
         from . import sharding
         rank, world = sharding.world_info()
         if world > 1 and not getattr(self, '_in_shard', False):
+            # contiguous shards; the decoded float32 points go to rank 0 with one (counts, rows) gather -- the other ranks
+            # return None (rank 0 writes the file, decompress_octree.py:111-113)
             lo, hi = sharding.shard_range(len(blocks), rank, world)
             self._in_shard = True
             try:
-                local = self.decompress_blocks(sess, blocks[lo:hi], x_shape, debug)
+                local, dbg = self.decompress_blocks(sess, blocks[lo:hi], x_shape, debug)
             finally:
                 self._in_shard = False
-            parts = sharding.gather_objects(local)
-            return [b for p in parts for b in p[0]], [d for p in parts for d in p[1]]
+            counts = sharding.all_gather_rows(np.array([[len(b)] for b in local], np.int64).reshape(-1, 1))[:, 0]
+            flat = sharding.gather_rows(np.vstack(local).astype(np.float32) if len(local) else np.zeros((0, 3), np.float32))
+            if rank != 0:
+                return None, dbg
+            off = np.concatenate([[0], np.cumsum(counts)])
+            return [flat[off[j]:off[j + 1]] for j in range(len(blocks))], dbg
         ctx = self._ctx(sess)
         dhw = self._spatial(x_shape)
         chunks = [blocks[c0:c0 + self.batch_size] for c0 in range(0, len(blocks), self.batch_size)]

@@ -290,7 +290,10 @@ def convert_variables(variables, model):
                     out[key] = np.ascontiguousarray(layer[part], np.float32)
                 else:
                     assert part not in layer, f'{prefix}/{i}: unexpected {part} in the checkpoint (layer order mismatch?)'
-    assert taken[id(fwd)] == len(fwd) and taken[id(tr)] == len(tr), \
+    # a decoder-only model (model.decompress(), model_types.py:297-309,393-411) has no analysis / hyper-analysis transform:
+    # the checkpoint's conv3d* layers are simply not needed; the transposed pool keeps its order (synthesis, hyper-synthesis)
+    has_analysis = any(k.startswith('analysis/') for k in want)
+    assert (taken[id(fwd)] == len(fwd) or not has_analysis) and taken[id(tr)] == len(tr), \
         f'unused conv layers in the checkpoint: {len(fwd) - taken[id(fwd)]} conv3d, {len(tr) - taken[id(tr)]} conv3d_transpose'
     # factorized prior: parameters as stored; the integer tables of the checkpoint win over recomputed ones (bit-exact rate)
     for k, v in eb.items():

@@ -59,6 +59,6 @@ def test_cli_missing_checkpoint_fails_like_reference(tmp_path):
     pc_io.write_df(src, pc_io.pa_to_df(_cloud(64, 1)))
     p = subprocess.run([sys.executable, '-m', 'pcc_geo_cnn_v2_amd.compress_octree', '--input_files', src, '--output_files',
                         str(tmp_path / 'x.bin'), '--checkpoint_dir', str(tmp_path / 'none'), '--model_config', 'c3p',
-                        '--resolution', '64', '--octree_level', '1'], cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT),
+                        '--resolution', '64', '--octree_level', '1', '--opt_metrics', 'd1_mse'], cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT),
                        capture_output=True, text=True)
     assert p.returncode != 0 and 'was not found' in p.stderr

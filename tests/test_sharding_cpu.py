@@ -45,12 +45,54 @@ def test_shard_range_is_a_partition():
 def test_two_rank_sharded_compress_equals_single_process(tmp_path):
     two = _run(2, str(tmp_path / 'w2'))
     one = _run(1, str(tmp_path / 'w1'))
+    # typed collectives
     for r in range(2):
-        assert [g['rank'] for g in two[r]['gather']] == [0, 1]
-        assert two[r]['gather'][1]['blob'] == bytes(range(4))
+        assert two[r]['rows'].tolist() == [[0, 1], [100, 101], [102, 103]]
+    assert two[0]['bytes'] == [bytes(range(1)), bytes(range(4))] and two[1]['bytes'] is None
+    assert two[0]['frows'].tolist() == [[0.5] * 3, [0.5] * 3, [1.5] * 3] and two[1]['frows'] is None
     assert two[0]['ranges'] == [(0, 0), (0, 1), (0, 3), (0, 4), (0, 7)]
     assert two[1]['ranges'] == [(0, 0), (1, 1), (3, 5), (4, 8), (7, 13)]
     assert one[0]['n_blocks'] > 4
-    for r in range(2):   # every rank holds the complete, block-ordered result
-        assert two[r]['data_list'] == one[0]['data_list']
-        assert np.isclose(two[r]['psnr'], one[0]['psnr'])
+    # rank 0 assembles exactly the single-process result (same strings, same thresholds, same block order, same points)
+    assert two[0]['data_list'] == one[0]['data_list'] and two[1]['data_list'] is None
+    assert np.array_equal(two[0]['full'], one[0]['full']) and two[1]['full'] is None
+    for r in range(2):   # the metrics come from all_reduce'd partial sums: every rank holds them, D1 exactly
+        for k, v in one[0]['metrics'].items():
+            assert two[r]['metrics'][k] == v, k
+    # normals + two optimisation groups, no point gather
+    assert two[0]['two']['data_list'] == one[0]['two']['data_list'] and two[1]['two']['data_list'] is None
+    for r in range(2):
+        assert two[r]['two']['idx'] == one[0]['two']['idx'] == [0, 1]
+        assert two[r]['two']['has_points'] == [False, False]
+        for ma, mb in zip(two[r]['two']['metrics'], one[0]['two']['metrics']):
+            for k, v in mb.items():
+                if k.startswith('d1'):
+                    assert ma[k] == v, k
+                else:   # D2 depends on which of several equidistant neighbours is taken (cross-shard ties: lowest rank)
+                    assert np.isclose(ma[k], v, rtol=0.05), (k, ma[k], v)
+    # decoder: all points on rank 0, in block order
+    assert two[1]['dec'] is None and len(two[0]['dec']) == one[0]['n_blocks']
+    for a, b in zip(two[0]['dec'], one[0]['dec']):
+        assert np.array_equal(a, b)
+
+
+def test_bench_self_launches_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus 2` with no launcher in the environment re-execs itself under torch.distributed.run and reports
+    n_gpus = 2 with both ranks' blocks (dry run: gloo on CPU, launcher + collective skeleton only); and it refuses to run
+    when fewer GPUs are visible than ranks instead of printing a mislabeled 1-GPU line."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '0', '--dry-run'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['dry_run'] is True and out['blocks_total'] == 2 * 3 * 32
+    # no GPUs here: the real bench must fail loudly, not fall back to one rank
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and 'refusing to run a mislabeled bench' in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{')]

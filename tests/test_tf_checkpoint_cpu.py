@@ -126,3 +126,38 @@ def test_gaussian_tables_of_another_tail_mass_are_accepted(tmp_path):
     gc = dst.conditional_bottleneck
     assert np.array_equal(gc.quantized_cdf, wide.quantized_cdf) and np.array_equal(gc.cdf_length, wide.cdf_length)
     assert np.array_equal(gc.offset, wide.offset)
+
+
+@pytest.mark.parametrize('cfg', ['c1', 'c3p'])
+def test_decoder_only_model_restores_from_a_tf_checkpoint(tmp_path, cfg):
+    """decompress_octree --checkpoint_dir <TF ckpt>: a model built with decompress() (model_types.py:297-309,393-411) has no
+    analysis / hyper-analysis transform; the checkpoint's conv3d* layers are skipped, the transposed layers keep their order."""
+    src = ModelConfigType[cfg].build()
+    src.compress([1, 1, 16, 16, 16])
+    rng = np.random.default_rng(5)
+    w = src.get_weights()
+    for k in w:
+        if k.split('/')[0] in ('analysis', 'synthesis', 'hyper_analysis', 'hyper_synthesis'):
+            w[k] = rng.standard_normal(w[k].shape).astype(np.float32)
+    src.set_weights({k: v for k, v in w.items() if not k.endswith(('quantized_cdf', 'cdf_length', 'offset'))})
+    ref = src.get_weights()
+    write_bundle(str(tmp_path / 'model.ckpt-9'), _tf_names(src), checksums=False)
+    open(tmp_path / 'checkpoint', 'w').write('model_checkpoint_path: "model.ckpt-9"\n')
+    dec = ModelConfigType[cfg].build()
+    dec.decompress()
+    dec.restore(str(tmp_path))
+    got = dec.get_weights()
+    assert not any(k.startswith(('analysis/', 'hyper_analysis/')) for k in got)
+    assert any(k.startswith('synthesis/') for k in got)
+    for k in got:
+        assert np.array_equal(got[k], ref[k]), k
+    # a decoder checkpoint with a missing transposed layer is still rejected
+    v = _tf_names(src)
+    drop = [k for k in v if '/conv3d_transpose_2/' in k]
+    for k in drop:
+        del v[k]
+    write_bundle(str(tmp_path / 'model.ckpt-9'), v, checksums=False)
+    bad = ModelConfigType[cfg].build()
+    bad.decompress()
+    with pytest.raises(AssertionError):
+        bad.restore(str(tmp_path))
