@@ -214,18 +214,21 @@ def main():
 
     run(max(args.warmup, 0)) if args.warmup > 0 else None
 
-    # live HIP-event timing of the dominant kernel (Conv3DTranspose 16->16 k3 s1 @64^3, 47 % of all MACs)
-    ops.PROFILE = {'match': lambda layer, shp: layer.cin == 16 and layer.cout == 16 and layer.k == 3 and shp[1] == RES,
-                   'events': []}
+    # live HIP-event timing of the dominant kernel on its launch stream: Conv3DTranspose 16->16 k3 s1 @64^3 + residual = layer 8
+    # of the c3p synthesis transform (its twin, layer 7, runs the same kernel without the residual read; together 47 % of all
+    # MACs).  The library records the events around that layer inside pcc_codec_encode / pcc_codec_decode_main.
+    from pcc_geo_cnn_v2_amd import _lib as L
+    DOM_LAYER = 8
+    ops.profile_select(ctx, L.PCC_NET_SYNTHESIS_PROGRESSIVE_V2, DOM_LAYER)
     barrier()
     t0 = time.perf_counter()
     n_blocks, n_bytes, n_pts = run(args.steps)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    ev = ops.PROFILE['events']
-    ops.PROFILE = None
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = ops.profile_read(ctx)
+    ops.profile_select(ctx, -1, -1)
+    assert len(kern_ms) == 2 * args.steps * (BATCH // args.chunk), f'{len(kern_ms)} timed launches of the dominant layer'
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -246,7 +249,7 @@ def main():
         if winograd:
             # conv_wino.hip: F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap), RES+2 input planes per RES outputs
             exec_flops = flops_launch * 16.0 / 36.0 * (RES + 2) / RES
-            dom_kernel = 'conv16_wino_kernel<relu,clip> (Conv3DTranspose 16->16 k3 s1 @64^3, 4 launches per step)'
+            dom_kernel = 'conv16_wino_kernel<relu> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the decoder; layer 7 runs the same kernel: 4 launches per step)'
             dom_note = ('achieved/frac = fp32 MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3) in x-y + direct z: 16/36 * 66/64 of '
                         'the direct-convolution flops) / HIP-event launch time / dense fp32 MFMA peak; algorithmic_* restate it in the '
                         'direct-convolution flops of SURVEY.md 8d (what a direct kernel would have to sustain for the same time)')

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PCC_ABI_VERSION 1
+#define PCC_ABI_VERSION 2
 
 /* ---- errors / context ------------------------------------------------------------------ */
 #define PCC_OK 0
@@ -93,6 +93,101 @@ int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w_keras_host, flo
 int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w,
                const float* w_packed, const float* bias, const float* residual, float* out,
                void* stream);
+
+/* ---- batched graph: whole transforms and whole graph phases in ONE call ------------------------------------------
+ * The layer stacks of src/model_transforms.py:41-158 (one id per member of its TransformType enum, :161-169) run as a
+ * sequence of pcc_conv3d launches enqueued by the library on `stream`; the reference runs them as one Keras
+ * `layer(tensor)` call inside sess.run (src/model_types.py:289-293,379-388,405-408).  ResidualLayer mode 'add' only
+ * (the mode every config uses); 'concat' stays available through pcc_conv3d's out_cstride/out_coffset.               */
+#define PCC_NET_ANALYSIS_V1 0               /* model_transforms.py:41-48   */
+#define PCC_NET_SYNTHESIS_V1 1              /* :51-59                      */
+#define PCC_NET_ANALYSIS_V2 2               /* :84-95                      */
+#define PCC_NET_SYNTHESIS_V2 3              /* :98-109                     */
+#define PCC_NET_ANALYSIS_PROGRESSIVE_V2 4   /* :112-123                    */
+#define PCC_NET_SYNTHESIS_PROGRESSIVE_V2 5  /* :126-137                    */
+#define PCC_NET_HYPER_ANALYSIS 6            /* :140-147                    */
+#define PCC_NET_HYPER_SYNTHESIS 7           /* :150-158                    */
+
+/* Number of conv layers of a transform (conv_layers() order = Keras construction order), or <0. */
+int32_t pcc_network_num_layers(int32_t transform, int32_t filters);
+/* Geometry of layer `layer` (Cin, Cout, k, stride, transposed, flags; N/D/H/W left 0) and its role in a residual block:
+ * 0 plain, 1 its output is the block's `tensor1`, 2 `tensor1` is added after its activation (model_transforms.py:30-36). */
+int pcc_network_layer(int32_t transform, int32_t filters, int32_t layer, pcc_conv_desc* d, int32_t* residual_role);
+/* Weight upload -- replaces saver.restore's variable placement (src/compress_octree.py:90-92).  The blob holds, per layer,
+ * the Keras-layout kernel, its MFMA/Winograd fragment image and the bias.  It lives in CALLER-owned device memory of
+ * pcc_weights_blob_floats() floats; pcc_weights_pack builds the same image on the host.  kernels[i] / biases[i]: host
+ * pointers in conv_layers() order (biases[i] ignored for layers without bias).  Synchronous (model-load time).          */
+size_t pcc_weights_blob_floats(int32_t transform, int32_t filters);
+int pcc_weights_pack(int32_t transform, int32_t filters, const float* const* kernels, const float* const* biases,
+                     float* blob_host);
+int pcc_weights_upload(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* const* kernels,
+                       const float* const* biases, float* blob_device, void* stream);
+/* Activations workspace (caller-owned device memory) for an input of N x D x H x W voxels, and the output size.          */
+size_t pcc_network_workspace_bytes(int32_t transform, int32_t filters, int32_t N, int32_t D, int32_t H, int32_t W);
+int pcc_network_out_dims(int32_t transform, int32_t filters, int32_t D, int32_t H, int32_t W, int32_t* OD, int32_t* OH,
+                         int32_t* OW, int32_t* OC);
+/* y = transform(x).  x: (N,D,H,W,Cin) with Cin = 1 for the analysis transforms, `filters` otherwise; y: NDHWC of
+ * pcc_network_out_dims.  layer_flags: 0 or PCC_CONV_F16 (every layer); final_flags: 0 or PCC_CONV_CLIP01 (last layer).
+ * Results are bit-identical to the same layers issued one by one through pcc_conv3d.                                      */
+int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x, int32_t N,
+                        int32_t D, int32_t H, int32_t W, float* y, void* workspace, size_t workspace_bytes,
+                        int32_t layer_flags, int32_t final_flags, void* stream);
+/* The same call restricted to one family: PCC_ERR_ARG when `transform` is of another family.               */
+int pcc_network_forward_analysis(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x,
+                                 int32_t N, int32_t D, int32_t H, int32_t W, float* y, void* workspace,
+                                 size_t workspace_bytes, int32_t layer_flags, int32_t final_flags, void* stream);
+int pcc_network_forward_synthesis(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x,
+                                  int32_t N, int32_t D, int32_t H, int32_t W, float* y, void* workspace,
+                                  size_t workspace_bytes, int32_t layer_flags, int32_t final_flags, void* stream);
+int pcc_network_forward_hyper_a(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x,
+                                int32_t N, int32_t D, int32_t H, int32_t W, float* y, void* workspace,
+                                size_t workspace_bytes, int32_t layer_flags, int32_t final_flags, void* stream);
+int pcc_network_forward_hyper_s(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x,
+                                int32_t N, int32_t D, int32_t H, int32_t W, float* y, void* workspace,
+                                size_t workspace_bytes, int32_t layer_flags, int32_t final_flags, void* stream);
+
+/* Graph phases of CompressionModelV1 / V2 (src/model_types.py:283-309, :371-411): the GPU part of compress() and of
+ * decompress() in one call each; the range coder (host) sits between them.  Device pointers, NDHWC, caller-owned.        */
+typedef struct {
+    int32_t version;          /* 1 = CompressionModelV1 (factorized prior on y), 2 = V2 (hyperprior)                     */
+    int32_t filters;
+    int32_t analysis, synthesis;            /* PCC_NET_* ids; analysis < 0 for a decoder-only model                      */
+    const float* w_analysis;                /* weight blobs (pcc_weights_upload); NULL where the transform is absent     */
+    const float* w_synthesis;
+    const float* w_hyper_analysis;
+    const float* w_hyper_synthesis;
+    const float* medians;                   /* (filters,) EntropyBottleneck medians                                      */
+    const float* scale_table;               /* (scale_levels,) GaussianConditional scale table (V2)                      */
+    int32_t scale_levels;
+    int32_t round_mode;                     /* PCC_ROUND_*                                                               */
+} pcc_codec_desc;
+size_t pcc_codec_workspace_bytes(const pcc_codec_desc* c, int32_t N, int32_t D, int32_t H, int32_t W);
+/* compress graph on N blocks: x (N,D,H,W) -> y, [z, zsym, z_hat, sigma, idx,] ysym, y_hat, x_hat (N,D,H,W; final_flags =
+ * PCC_CONV_CLIP01 applies np.clip(x_hat,0,1), model_types.py:202).  The V2-only tensors may be NULL for version 1.
+ * thr != NULL (fixed-threshold policy, model_opt.py:27-31) also extracts the encoder-side point lists in the same call:
+ * thr, xyz, counts, cap, scratch as in pcc_threshold_compact with clip = 1.  symbols_ready: NULL or a hipEvent_t the
+ * library records on `stream` as soon as zsym / idx / ysym are final, i.e. BEFORE the synthesis transform is enqueued, so
+ * that the device->host copy and the host range coder overlap the synthesis.                                               */
+int pcc_codec_encode(pcc_ctx* ctx, const pcc_codec_desc* c, const float* x, int32_t N, int32_t D, int32_t H, int32_t W,
+                     float* y, float* z, int32_t* zsym, float* z_hat, float* sigma, int32_t* idx, int32_t* ysym,
+                     float* y_hat, float* x_hat, const float* thr, float* xyz, int32_t* counts, int64_t cap,
+                     int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags, int32_t final_flags,
+                     void* symbols_ready, void* stream);
+/* decompress graph, V2 first phase (model_types.py:403-406): zsym -> z_hat -> sigma -> idx.                               */
+int pcc_codec_decode_hyper(pcc_ctx* ctx, const pcc_codec_desc* c, const int32_t* zsym, int32_t N, int32_t D, int32_t H,
+                           int32_t W, float* z_hat, float* sigma, int32_t* idx, void* workspace, size_t workspace_bytes,
+                           int32_t layer_flags, void* stream);
+/* decompress graph, main phase (:305-307 / :407-408): ysym -> y_hat -> x_hat and, when thr != NULL, the unclipped
+ * thresholding + compaction of :232-234 (arguments as pcc_threshold_compact).                                              */
+int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, const int32_t* ysym, int32_t N, int32_t D, int32_t H,
+                          int32_t W, float* y_hat, float* x_hat, const float* thr, float* xyz, int32_t* counts, int64_t cap,
+                          int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags, void* stream);
+
+/* Live kernel timing: HIP events recorded on the launch stream around layer `layer` of transform `transform` in every
+ * pcc_network_forward / pcc_codec_* call (transform < 0 switches it off); pcc_profile_read waits for the recorded events,
+ * returns their durations in milliseconds (at most `cap`) and clears the list.  The events belong to the context.        */
+int pcc_profile_select(pcc_ctx* ctx, int32_t transform, int32_t layer);
+int pcc_profile_read(pcc_ctx* ctx, float* ms, int32_t cap, int32_t* n);
 
 /* ---- entropy-model element-wise kernels -------------------------------------------------
  * Quantisation of tfc.EntropyBottleneck / tfc.GaussianConditional `_quantize`

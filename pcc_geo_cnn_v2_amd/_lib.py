@@ -21,7 +21,15 @@ EXPORTS = [
     'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
     'pcc_range_encode_batch', 'pcc_range_decode_batch', 'pcc_pmf_to_quantized_cdf',
     'pcc_d1_search_workspace_bytes', 'pcc_d1_threshold_stats', 'pcc_octree_bucket',
+    'pcc_network_num_layers', 'pcc_network_layer', 'pcc_weights_blob_floats', 'pcc_weights_pack', 'pcc_weights_upload',
+    'pcc_network_workspace_bytes', 'pcc_network_out_dims', 'pcc_network_forward', 'pcc_network_forward_analysis',
+    'pcc_network_forward_synthesis', 'pcc_network_forward_hyper_a', 'pcc_network_forward_hyper_s',
+    'pcc_codec_workspace_bytes', 'pcc_codec_encode', 'pcc_codec_decode_hyper', 'pcc_codec_decode_main',
+    'pcc_profile_select', 'pcc_profile_read',
 ]
+ABI_VERSION = 2
+(PCC_NET_ANALYSIS_V1, PCC_NET_SYNTHESIS_V1, PCC_NET_ANALYSIS_V2, PCC_NET_SYNTHESIS_V2, PCC_NET_ANALYSIS_PROGRESSIVE_V2,
+ PCC_NET_SYNTHESIS_PROGRESSIVE_V2, PCC_NET_HYPER_ANALYSIS, PCC_NET_HYPER_SYNTHESIS) = range(8)
 
 
 class ConvDesc(C.Structure):
@@ -33,6 +41,13 @@ class CdfTable(C.Structure):
     _fields_ = [('cdf', C.POINTER(C.c_int32)), ('cdf_size', C.POINTER(C.c_int32)), ('offset', C.POINTER(C.c_int32)),
                 ('rows', C.c_int32), ('cdf_stride', C.c_int32), ('precision', C.c_int32),
                 ('overflow_width', C.c_int32)]
+
+
+class CodecDesc(C.Structure):
+    _fields_ = [('version', C.c_int32), ('filters', C.c_int32), ('analysis', C.c_int32), ('synthesis', C.c_int32),
+                ('w_analysis', C.c_void_p), ('w_synthesis', C.c_void_p), ('w_hyper_analysis', C.c_void_p),
+                ('w_hyper_synthesis', C.c_void_p), ('medians', C.c_void_p), ('scale_table', C.c_void_p),
+                ('scale_levels', C.c_int32), ('round_mode', C.c_int32)]
 
 
 class PccError(RuntimeError):
@@ -84,8 +99,31 @@ def lib():
     L.pcc_d1_threshold_stats.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.pcc_octree_bucket.argtypes = [vp, C.c_int64, i32, i32, i32, vp, vp]
     L.pcc_octree_bucket.restype = C.c_int64
+    L.pcc_network_num_layers.argtypes = [i32, i32]
+    L.pcc_network_layer.argtypes = [i32, i32, i32, C.POINTER(ConvDesc), C.POINTER(i32)]
+    L.pcc_weights_blob_floats.argtypes = [i32, i32]
+    L.pcc_weights_blob_floats.restype = sz
+    L.pcc_weights_pack.argtypes = [i32, i32, vp, vp, vp]
+    L.pcc_weights_upload.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    L.pcc_network_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32]
+    L.pcc_network_workspace_bytes.restype = sz
+    L.pcc_network_out_dims.argtypes = [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    for fn in (L.pcc_network_forward, L.pcc_network_forward_analysis, L.pcc_network_forward_synthesis,
+               L.pcc_network_forward_hyper_a, L.pcc_network_forward_hyper_s):
+        fn.argtypes = [vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, sz, i32, i32, vp]
+    L.pcc_codec_workspace_bytes.argtypes = [C.POINTER(CodecDesc), i32, i32, i32, i32]
+    L.pcc_codec_workspace_bytes.restype = sz
+    L.pcc_codec_encode.argtypes = [vp, C.POINTER(CodecDesc), vp, i32, i32, i32, i32] + [vp] * 9 + [vp, vp, vp, C.c_int64, vp] + \
+        [vp, sz, i32, i32, vp, vp]
+    L.pcc_codec_decode_hyper.argtypes = [vp, C.POINTER(CodecDesc), vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, i32, vp]
+    L.pcc_codec_decode_main.argtypes = [vp, C.POINTER(CodecDesc), vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, C.c_int64, vp,
+                                        vp, sz, i32, vp]
+    L.pcc_profile_select.argtypes = [vp, i32, i32]
+    L.pcc_profile_read.argtypes = [vp, vp, i32, C.POINTER(i32)]
     for name in EXPORTS:
         getattr(L, name)          # AttributeError here = the shared object is older than the header
+    if L.pcc_abi_version() != ABI_VERSION:
+        raise PccError(f'{LIB_PATH} has ABI version {L.pcc_abi_version()}, this package needs {ABI_VERSION}: rebuild it')
     _lib = L
     return L
 

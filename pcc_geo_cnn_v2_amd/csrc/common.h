@@ -11,7 +11,9 @@ struct pcc_ctx {
     int device;
     int num_cu;
     hipDeviceProp_t prop;
+    void* profile = nullptr;     // live kernel timing state of network.hip (pcc_profile_select / pcc_profile_read)
 };
+void pcc_profile_free(pcc_ctx* ctx);
 
 void pcc_set_error(const char* fmt, ...);
 

@@ -47,6 +47,7 @@ PCC_API int pcc_ctx_create(int device, pcc_ctx** out) {
 }
 
 PCC_API int pcc_ctx_destroy(pcc_ctx* ctx) {
+    if (ctx) pcc_profile_free(ctx);
     delete ctx;
     return PCC_OK;
 }

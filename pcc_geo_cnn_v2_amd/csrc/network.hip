@@ -1,0 +1,438 @@
+// Whole-transform and whole-graph entry points of the C ABI (include/pcc_geo.h, "batched graph" section).
+//
+// The layer stacks of /root/reference/src/model_transforms.py:41-158 and the graph wiring of
+// /root/reference/src/model_types.py:283-309 (V1) / :371-411 (V2) as HOST code that enqueues the kernels of this library on
+// one stream: one call per transform (pcc_network_forward) or per graph phase (pcc_codec_*), instead of one ctypes call per
+// layer.  All device memory belongs to the caller: the packed weight blob, the activations workspace and every output.
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct LayerSpec {
+    bool transposed;
+    int cout, k, stride;
+    bool bias, relu;
+    int res;          // 0 none, 1 output is kept as the residual of the block ("tensor1"), 2 residual added after the activation
+};
+
+// AnalysisBlock :62-70 / SynthesisBlock :73-81 with ResidualLayer.call :30-38 (mode 'add'): t1 = L0(x); t = L2(L1(t1)); t1 + t
+void add_block(std::vector<LayerSpec>& v, bool tr, int f) {
+    v.push_back({tr, f, 3, 2, true, true, 1});
+    v.push_back({tr, f, 3, 1, true, true, 0});
+    v.push_back({tr, f, 3, 1, true, true, 2});
+}
+
+bool build_layers(int transform, int F, std::vector<LayerSpec>& v, int* cin0) {
+    v.clear();
+    if (F <= 0) return false;
+    *cin0 = F;
+    switch (transform) {
+        case PCC_NET_ANALYSIS_V1:             // :41-48
+            *cin0 = 1;
+            v.push_back({false, F, 9, 2, true, true, 0});
+            v.push_back({false, F, 5, 2, true, true, 0});
+            v.push_back({false, F, 5, 2, false, false, 0});
+            return true;
+        case PCC_NET_SYNTHESIS_V1:            // :51-59 (the final activation is ReLU, :58)
+            v.push_back({true, F, 5, 2, true, true, 0});
+            v.push_back({true, F, 5, 2, true, true, 0});
+            v.push_back({true, 1, 9, 2, true, true, 0});
+            return true;
+        case PCC_NET_ANALYSIS_V2:             // :84-95
+            *cin0 = 1;
+            add_block(v, false, F / 2); add_block(v, false, F); add_block(v, false, F);
+            v.push_back({false, F, 3, 1, false, false, 0});
+            return true;
+        case PCC_NET_SYNTHESIS_V2:            // :98-109
+            add_block(v, true, F); add_block(v, true, F); add_block(v, true, F / 2);
+            v.push_back({true, 1, 3, 1, true, true, 0});
+            return true;
+        case PCC_NET_ANALYSIS_PROGRESSIVE_V2: // :112-123
+            *cin0 = 1;
+            add_block(v, false, F / 4); add_block(v, false, F / 2); add_block(v, false, F);
+            v.push_back({false, F, 3, 1, false, false, 0});
+            return true;
+        case PCC_NET_SYNTHESIS_PROGRESSIVE_V2:  // :126-137
+            add_block(v, true, F); add_block(v, true, F / 2); add_block(v, true, F / 4);
+            v.push_back({true, 1, 3, 1, true, true, 0});
+            return true;
+        case PCC_NET_HYPER_ANALYSIS:          // :140-147
+            v.push_back({false, F, 3, 1, true, true, 0});
+            v.push_back({false, F, 3, 2, true, true, 0});
+            v.push_back({false, F, 3, 1, false, false, 0});
+            return true;
+        case PCC_NET_HYPER_SYNTHESIS:         // :150-158 (all three bias + ReLU)
+            v.push_back({true, F, 3, 1, true, true, 0});
+            v.push_back({true, F, 3, 2, true, true, 0});
+            v.push_back({true, F, 3, 1, true, true, 0});
+            return true;
+        default: return false;
+    }
+}
+
+inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }   // blob segments start on 256-byte boundaries
+
+struct LayerImage { size_t w, pk, pk_floats, b; int cin; };            // float offsets inside the blob
+
+pcc_conv_desc layer_desc(const LayerSpec& L, int cin, int N, int D, int H, int W, int flags) {
+    pcc_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = N; d.D = D; d.H = H; d.W = W; d.Cin = cin; d.Cout = L.cout; d.k = L.k; d.stride = L.stride;
+    d.transposed = L.transposed ? 1 : 0;
+    d.flags = flags | (L.bias ? PCC_CONV_BIAS : 0) | (L.relu ? PCC_CONV_RELU : 0) | (L.res == 2 ? PCC_CONV_ADD : 0);
+    d.impl = PCC_IMPL_AUTO;
+    return d;
+}
+
+// The packed image of a layer depends on (Cin, Cout, k, stride, transposed) only; 64^3 is a size every fast kernel covers.
+size_t blob_layout(const std::vector<LayerSpec>& v, int cin0, std::vector<LayerImage>& im) {
+    size_t off = 0;
+    int cin = cin0;
+    im.clear();
+    for (const LayerSpec& L : v) {
+        LayerImage I;
+        I.cin = cin;
+        I.w = off; off += align64((size_t)L.k * L.k * L.k * cin * L.cout);
+        const pcc_conv_desc d = layer_desc(L, cin, 1, 64, 64, 64, 0);
+        I.pk_floats = pcc_conv_packed_floats(&d);
+        I.pk = off; off += align64(I.pk_floats);
+        I.b = off; off += L.bias ? align64((size_t)L.cout) : 0;
+        im.push_back(I);
+        cin = L.cout;
+    }
+    return off;
+}
+
+void out_dims(const LayerSpec& L, int& D, int& H, int& W) {
+    if (L.transposed) { D *= L.stride; H *= L.stride; W *= L.stride; }
+    else { D = pcc_same_out(D, L.stride); H = pcc_same_out(H, L.stride); W = pcc_same_out(W, L.stride); }
+}
+
+// activations: three rotating buffers (x -> t1 -> t -> t1 + t reuses x's buffer), each as large as the largest intermediate
+size_t act_floats(const std::vector<LayerSpec>& v, int N, int D, int H, int W) {
+    size_t mx = 0;
+    for (size_t i = 0; i + 1 < v.size(); ++i) {
+        out_dims(v[i], D, H, W);
+        const size_t n = (size_t)N * D * H * W * v[i].cout;
+        if (n > mx) mx = n;
+    }
+    return align64(mx);
+}
+
+struct Profile {
+    int transform = -1, layer = -1;
+    std::vector<hipEvent_t> ev;     // pairs (start, stop)
+    size_t used = 0;
+};
+
+}  // namespace
+
+// per-context profiling state lives behind the context (ctx.hip owns the struct; only this file touches `profile`)
+static Profile* prof_of(pcc_ctx* ctx) {
+    if (!ctx->profile) ctx->profile = new Profile();
+    return (Profile*)ctx->profile;
+}
+void pcc_profile_free(pcc_ctx* ctx) {
+    Profile* p = (Profile*)ctx->profile;
+    if (!p) return;
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+    ctx->profile = nullptr;
+}
+
+PCC_API int32_t pcc_network_num_layers(int32_t transform, int32_t filters) {
+    std::vector<LayerSpec> v;
+    int c0;
+    if (!build_layers(transform, filters, v, &c0)) { pcc_set_error("pcc_network_num_layers: unknown transform %d / filters %d", transform, filters); return PCC_ERR_ARG; }
+    return (int32_t)v.size();
+}
+
+PCC_API int pcc_network_layer(int32_t transform, int32_t filters, int32_t layer, pcc_conv_desc* d, int32_t* residual_role) {
+    std::vector<LayerSpec> v;
+    int c0;
+    PCC_REQUIRE(d && build_layers(transform, filters, v, &c0), "pcc_network_layer: bad transform / filters");
+    PCC_REQUIRE(layer >= 0 && layer < (int)v.size(), "pcc_network_layer: layer %d out of range", layer);
+    int cin = c0;
+    for (int i = 0; i < layer; ++i) cin = v[i].cout;
+    *d = layer_desc(v[layer], cin, 0, 0, 0, 0, 0);
+    if (residual_role) *residual_role = v[layer].res;
+    return PCC_OK;
+}
+
+PCC_API size_t pcc_weights_blob_floats(int32_t transform, int32_t filters) {
+    std::vector<LayerSpec> v;
+    std::vector<LayerImage> im;
+    int c0;
+    if (!build_layers(transform, filters, v, &c0)) return 0;
+    return blob_layout(v, c0, im);
+}
+
+PCC_API int pcc_weights_pack(int32_t transform, int32_t filters, const float* const* kernels, const float* const* biases,
+                             float* blob_host) {
+    std::vector<LayerSpec> v;
+    std::vector<LayerImage> im;
+    int c0;
+    PCC_REQUIRE(kernels && blob_host && build_layers(transform, filters, v, &c0), "pcc_weights_pack: bad argument");
+    const size_t total = blob_layout(v, c0, im);
+    memset(blob_host, 0, total * sizeof(float));
+    for (size_t i = 0; i < v.size(); ++i) {
+        const LayerSpec& L = v[i];
+        PCC_REQUIRE(kernels[i], "pcc_weights_pack: kernel of layer %d is NULL", (int)i);
+        memcpy(blob_host + im[i].w, kernels[i], (size_t)L.k * L.k * L.k * im[i].cin * L.cout * sizeof(float));
+        if (im[i].pk_floats) {
+            const pcc_conv_desc d = layer_desc(L, im[i].cin, 1, 64, 64, 64, 0);
+            const int rc = pcc_conv_pack_weights(&d, kernels[i], blob_host + im[i].pk);
+            if (rc != PCC_OK) return rc;
+        }
+        if (L.bias) {
+            PCC_REQUIRE(biases && biases[i], "pcc_weights_pack: bias of layer %d is NULL", (int)i);
+            memcpy(blob_host + im[i].b, biases[i], (size_t)L.cout * sizeof(float));
+        }
+    }
+    return PCC_OK;
+}
+
+PCC_API int pcc_weights_upload(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* const* kernels,
+                               const float* const* biases, float* blob_device, void* stream) {
+    PCC_REQUIRE(ctx && blob_device, "pcc_weights_upload: NULL argument");
+    const size_t n = pcc_weights_blob_floats(transform, filters);
+    PCC_REQUIRE(n > 0, "pcc_weights_upload: unknown transform %d / filters %d", transform, filters);
+    std::vector<float> host(n);
+    const int rc = pcc_weights_pack(transform, filters, kernels, biases, host.data());
+    if (rc != PCC_OK) return rc;
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    // pageable source: the copy is staged by the runtime and complete on return (model load time, not the hot path)
+    PCC_CHECK_HIP(hipMemcpyAsync(blob_device, host.data(), n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    PCC_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PCC_OK;
+}
+
+PCC_API size_t pcc_network_workspace_bytes(int32_t transform, int32_t filters, int32_t N, int32_t D, int32_t H, int32_t W) {
+    std::vector<LayerSpec> v;
+    int c0;
+    if (!build_layers(transform, filters, v, &c0) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return 3 * act_floats(v, N, D, H, W) * sizeof(float) + 256;
+}
+
+PCC_API int pcc_network_out_dims(int32_t transform, int32_t filters, int32_t D, int32_t H, int32_t W, int32_t* OD, int32_t* OH,
+                                 int32_t* OW, int32_t* OC) {
+    std::vector<LayerSpec> v;
+    int c0;
+    PCC_REQUIRE(OD && OH && OW && OC && build_layers(transform, filters, v, &c0), "pcc_network_out_dims: bad argument");
+    for (const LayerSpec& L : v) out_dims(L, D, H, W);
+    *OD = D; *OH = H; *OW = W; *OC = v.back().cout;
+    return PCC_OK;
+}
+
+PCC_API int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x, int32_t N,
+                                int32_t D, int32_t H, int32_t W, float* y, void* workspace, size_t workspace_bytes,
+                                int32_t layer_flags, int32_t final_flags, void* stream) {
+    std::vector<LayerSpec> v;
+    std::vector<LayerImage> im;
+    int c0;
+    PCC_REQUIRE(ctx && blob && x && y, "pcc_network_forward: NULL argument");
+    PCC_REQUIRE(build_layers(transform, filters, v, &c0), "pcc_network_forward: unknown transform %d / filters %d", transform, filters);
+    PCC_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "pcc_network_forward: non-positive dimension");
+    PCC_REQUIRE((layer_flags & ~PCC_CONV_F16) == 0 && (final_flags & ~PCC_CONV_CLIP01) == 0,
+                "pcc_network_forward: layer_flags may hold PCC_CONV_F16, final_flags PCC_CONV_CLIP01");
+    blob_layout(v, c0, im);
+    const size_t af = act_floats(v, N, D, H, W);
+    PCC_REQUIRE(v.size() == 1 || (workspace && workspace_bytes >= 3 * af * sizeof(float)),
+                "pcc_network_forward: workspace too small (need pcc_network_workspace_bytes)");
+    float* buf[3];
+    {   // 256-byte aligned start
+        uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+        for (int i = 0; i < 3; ++i) buf[i] = (float*)p + (size_t)i * af;
+        PCC_REQUIRE(v.size() == 1 || (uintptr_t)(buf[2] + af) <= (uintptr_t)workspace + workspace_bytes,
+                    "pcc_network_forward: workspace too small after alignment");
+    }
+    Profile* prof = ctx->profile ? (Profile*)ctx->profile : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const float* in = x;
+    const float* t1 = nullptr;
+    int cur = 0;                 // rotating buffer that receives the next output
+    int in_buf = -1, t1_buf = -1;
+    for (size_t i = 0; i < v.size(); ++i) {
+        const LayerSpec& L = v[i];
+        const bool last = i + 1 == v.size();
+        pcc_conv_desc d = layer_desc(L, im[i].cin, N, D, H, W, layer_flags | (last ? final_flags : 0));
+        float* out;
+        if (last) out = y;
+        else {
+            // pick a buffer that holds neither the input nor the pending residual
+            while (cur == in_buf || cur == t1_buf) cur = (cur + 1) % 3;
+            out = buf[cur];
+        }
+        const bool timed = prof && prof->transform == transform && prof->layer == (int)i;
+        if (timed) {
+            if (prof->used + 2 > prof->ev.size()) {
+                PCC_REQUIRE(prof->ev.size() < 8192, "pcc_network_forward: profile buffer full (pcc_profile_read drains it)");
+                for (int e = 0; e < 2; ++e) { hipEvent_t ev; PCC_CHECK_HIP(hipEventCreate(&ev)); prof->ev.push_back(ev); }
+            }
+            PCC_CHECK_HIP(hipEventRecord(prof->ev[prof->used], st));
+        }
+        const int rc = pcc_conv3d(ctx, &d, in, blob + im[i].w, im[i].pk_floats ? blob + im[i].pk : nullptr,
+                                  L.bias ? blob + im[i].b : nullptr, L.res == 2 ? t1 : nullptr, out, stream);
+        if (rc != PCC_OK) return rc;
+        if (timed) { PCC_CHECK_HIP(hipEventRecord(prof->ev[prof->used + 1], st)); prof->used += 2; }
+        out_dims(L, D, H, W);
+        if (L.res == 1) { t1 = out; t1_buf = last ? -1 : cur; }
+        if (L.res == 2) { t1 = nullptr; t1_buf = -1; }
+        in = out;
+        in_buf = last ? -1 : cur;
+    }
+    return PCC_OK;
+}
+
+// The four names of SURVEY.md §8b: the same call restricted to one family of transforms.
+#define PCC_NET_FAMILY(NAME, COND, WHAT)                                                                                         \
+    PCC_API int NAME(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x, int32_t N, int32_t D, \
+                     int32_t H, int32_t W, float* y, void* workspace, size_t workspace_bytes, int32_t layer_flags,              \
+                     int32_t final_flags, void* stream) {                                                                       \
+        PCC_REQUIRE(COND, #NAME ": transform %d is not " WHAT, transform);                                                      \
+        return pcc_network_forward(ctx, transform, filters, blob, x, N, D, H, W, y, workspace, workspace_bytes, layer_flags,    \
+                                   final_flags, stream);                                                                        \
+    }
+PCC_NET_FAMILY(pcc_network_forward_analysis, transform == PCC_NET_ANALYSIS_V1 || transform == PCC_NET_ANALYSIS_V2 || transform == PCC_NET_ANALYSIS_PROGRESSIVE_V2, "an analysis transform")
+PCC_NET_FAMILY(pcc_network_forward_synthesis, transform == PCC_NET_SYNTHESIS_V1 || transform == PCC_NET_SYNTHESIS_V2 || transform == PCC_NET_SYNTHESIS_PROGRESSIVE_V2, "a synthesis transform")
+PCC_NET_FAMILY(pcc_network_forward_hyper_a, transform == PCC_NET_HYPER_ANALYSIS, "the hyper-analysis transform")
+PCC_NET_FAMILY(pcc_network_forward_hyper_s, transform == PCC_NET_HYPER_SYNTHESIS, "the hyper-synthesis transform")
+
+// ---- live kernel timing (bench.py's roofline object) ----------------------------------------------------------------------
+PCC_API int pcc_profile_select(pcc_ctx* ctx, int32_t transform, int32_t layer) {
+    PCC_REQUIRE(ctx, "pcc_profile_select: ctx is NULL");
+    if (transform < 0) { if (ctx->profile) { Profile* p = (Profile*)ctx->profile; p->transform = p->layer = -1; p->used = 0; } return PCC_OK; }
+    Profile* p = prof_of(ctx);
+    p->transform = transform; p->layer = layer; p->used = 0;
+    return PCC_OK;
+}
+
+PCC_API int pcc_profile_read(pcc_ctx* ctx, float* ms, int32_t cap, int32_t* n) {
+    PCC_REQUIRE(ctx && n && (ms || cap == 0), "pcc_profile_read: NULL argument");
+    *n = 0;
+    Profile* p = (Profile*)ctx->profile;
+    if (!p) return PCC_OK;
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    for (size_t i = 0; i + 1 < p->used && *n < cap; i += 2) {
+        PCC_CHECK_HIP(hipEventSynchronize(p->ev[i + 1]));
+        PCC_CHECK_HIP(hipEventElapsedTime(&ms[*n], p->ev[i], p->ev[i + 1]));
+        ++*n;
+    }
+    p->used = 0;
+    return PCC_OK;
+}
+
+// ---- graph phases (src/model_types.py:283-309 V1, :371-411 V2) ------------------------------------------------------------
+static int check_codec(const pcc_codec_desc* c) {
+    PCC_REQUIRE(c && (c->version == 1 || c->version == 2) && c->filters > 0, "pcc_codec: bad descriptor (version / filters)");
+    PCC_REQUIRE(c->w_synthesis && c->synthesis >= 0, "pcc_codec: the synthesis transform is required");
+    PCC_REQUIRE(c->version == 1 || (c->w_hyper_synthesis && c->scale_table && c->scale_levels >= 1),
+                "pcc_codec: version 2 needs the hyper-synthesis weights and the scale table");
+    PCC_REQUIRE(c->version == 2 || c->medians, "pcc_codec: version 1 needs the EntropyBottleneck medians");
+    return PCC_OK;
+}
+
+PCC_API size_t pcc_codec_workspace_bytes(const pcc_codec_desc* c, int32_t N, int32_t D, int32_t H, int32_t W) {
+    if (!c) return 0;
+    size_t m = pcc_network_workspace_bytes(c->synthesis, c->filters, N, D / 8, H / 8, W / 8);
+    if (c->analysis >= 0) { const size_t a = pcc_network_workspace_bytes(c->analysis, c->filters, N, D, H, W); if (a > m) m = a; }
+    if (c->version == 2) {
+        size_t a = pcc_network_workspace_bytes(PCC_NET_HYPER_SYNTHESIS, c->filters, N, D / 16, H / 16, W / 16);
+        if (a > m) m = a;
+        a = pcc_network_workspace_bytes(PCC_NET_HYPER_ANALYSIS, c->filters, N, D / 8, H / 8, W / 8);
+        if (a > m) m = a;
+    }
+    return m;
+}
+
+// x (N,D,H,W) occupancy -> every tensor of the compress graph.  Outputs are caller-owned device buffers, NDHWC:
+//   y (N,D/8..,F) float, ysym int32, y_hat float, x_hat (N,D,H,W) float (unclipped; final_flags = PCC_CONV_CLIP01 clips);
+//   V2 only: z (N,D/16..,F), zsym, z_hat, sigma (N,D/8..,F) float, idx int32.
+// thr != NULL additionally runs the encoder-side thresholding + compaction (clipped x_hat) like pcc_threshold_compact.
+PCC_API int pcc_codec_encode(pcc_ctx* ctx, const pcc_codec_desc* c, const float* x, int32_t N, int32_t D, int32_t H, int32_t W,
+                             float* y, float* z, int32_t* zsym, float* z_hat, float* sigma, int32_t* idx, int32_t* ysym,
+                             float* y_hat, float* x_hat, const float* thr, float* xyz, int32_t* counts, int64_t cap,
+                             int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags,
+                             int32_t final_flags, void* symbols_ready, void* stream) {
+    int rc = check_codec(c);
+    if (rc != PCC_OK) return rc;
+    PCC_REQUIRE(c->analysis >= 0 && c->w_analysis, "pcc_codec_encode: the analysis transform is required");
+    PCC_REQUIRE(ctx && x && y && ysym && y_hat && x_hat, "pcc_codec_encode: NULL argument");
+    PCC_REQUIRE(D % 8 == 0 && H % 8 == 0 && W % 8 == 0 && (c->version == 1 || (D % 16 == 0 && H % 16 == 0 && W % 16 == 0)),
+                "pcc_codec_encode: block edges must be multiples of 8 (V1) / 16 (V2)");
+    const int F = c->filters;
+    const size_t ny = (size_t)N * (D / 8) * (H / 8) * (W / 8) * F;
+    rc = pcc_network_forward(ctx, c->analysis, F, c->w_analysis, x, N, D, H, W, y, workspace, workspace_bytes, layer_flags, 0, stream);
+    if (rc != PCC_OK) return rc;
+    if (c->version == 1) {
+        rc = pcc_quantize(ctx, y, c->medians, ysym, y_hat, ny, F, c->round_mode, stream);
+        if (rc != PCC_OK) return rc;
+    } else {
+        PCC_REQUIRE(c->w_hyper_analysis && z && zsym && z_hat && sigma && idx, "pcc_codec_encode: version 2 needs the hyper tensors");
+        const size_t nz = (size_t)N * (D / 16) * (H / 16) * (W / 16) * F;
+        rc = pcc_network_forward(ctx, PCC_NET_HYPER_ANALYSIS, F, c->w_hyper_analysis, y, N, D / 8, H / 8, W / 8, z, workspace,
+                                 workspace_bytes, layer_flags, 0, stream);
+        if (rc != PCC_OK) return rc;
+        rc = pcc_quantize(ctx, z, c->medians, zsym, z_hat, nz, F, c->round_mode, stream);
+        if (rc != PCC_OK) return rc;
+        rc = pcc_network_forward(ctx, PCC_NET_HYPER_SYNTHESIS, F, c->w_hyper_synthesis, z_hat, N, D / 16, H / 16, W / 16, sigma,
+                                 workspace, workspace_bytes, layer_flags, 0, stream);
+        if (rc != PCC_OK) return rc;
+        rc = pcc_scale_to_index(ctx, sigma, c->scale_table, c->scale_levels, idx, ny, stream);
+        if (rc != PCC_OK) return rc;
+        rc = pcc_quantize(ctx, y, nullptr, ysym, y_hat, ny, F, c->round_mode, stream);
+        if (rc != PCC_OK) return rc;
+    }
+    // everything the range coder needs is final here: the caller's copy stream / host coder can start while the synthesis
+    // transform (most of the work) is still being enqueued and executed
+    if (symbols_ready) PCC_CHECK_HIP(hipEventRecord((hipEvent_t)symbols_ready, (hipStream_t)stream));
+    rc = pcc_network_forward(ctx, c->synthesis, F, c->w_synthesis, y_hat, N, D / 8, H / 8, W / 8, x_hat, workspace,
+                             workspace_bytes, layer_flags, final_flags, stream);
+    if (rc != PCC_OK || !thr) return rc;
+    // fixed-threshold policy (model_opt.py:27-31): the encoder-side point lists in the same call; the encoder clips (:202)
+    PCC_REQUIRE(xyz && counts && scratch, "pcc_codec_encode: thr given but xyz / counts / scratch is NULL");
+    return pcc_threshold_compact(ctx, x_hat, N, D, H, W, thr, 1, xyz, counts, cap, scratch, stream);
+}
+
+// V2 decoder, first phase (model_types.py:403-406): z symbols -> z_hat -> sigma -> indexes.
+PCC_API int pcc_codec_decode_hyper(pcc_ctx* ctx, const pcc_codec_desc* c, const int32_t* zsym, int32_t N, int32_t D, int32_t H,
+                                   int32_t W, float* z_hat, float* sigma, int32_t* idx, void* workspace, size_t workspace_bytes,
+                                   int32_t layer_flags, void* stream) {
+    int rc = check_codec(c);
+    if (rc != PCC_OK) return rc;
+    PCC_REQUIRE(c->version == 2 && ctx && zsym && z_hat && sigma && idx, "pcc_codec_decode_hyper: version-2 codec and non-NULL tensors");
+    PCC_REQUIRE(D % 16 == 0 && H % 16 == 0 && W % 16 == 0, "pcc_codec_decode_hyper: block edges must be multiples of 16");
+    const int F = c->filters;
+    const size_t nz = (size_t)N * (D / 16) * (H / 16) * (W / 16) * F, ny = (size_t)N * (D / 8) * (H / 8) * (W / 8) * F;
+    rc = pcc_dequantize(ctx, zsym, c->medians, z_hat, nz, F, stream);
+    if (rc != PCC_OK) return rc;
+    rc = pcc_network_forward(ctx, PCC_NET_HYPER_SYNTHESIS, F, c->w_hyper_synthesis, z_hat, N, D / 16, H / 16, W / 16, sigma,
+                             workspace, workspace_bytes, layer_flags, 0, stream);
+    if (rc != PCC_OK) return rc;
+    return pcc_scale_to_index(ctx, sigma, c->scale_table, c->scale_levels, idx, ny, stream);
+}
+
+// Decoder, main phase (model_types.py:305-307 V1, :407-408 V2): y symbols -> y_hat -> x_hat, then (optionally, thr != NULL)
+// the thresholding + order-preserving compaction of model_types.py:232-234 in the same call.
+PCC_API int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, const int32_t* ysym, int32_t N, int32_t D, int32_t H,
+                                  int32_t W, float* y_hat, float* x_hat, const float* thr, float* xyz, int32_t* counts,
+                                  int64_t cap, int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags,
+                                  void* stream) {
+    int rc = check_codec(c);
+    if (rc != PCC_OK) return rc;
+    PCC_REQUIRE(ctx && ysym && y_hat && x_hat, "pcc_codec_decode_main: NULL argument");
+    PCC_REQUIRE(D % 8 == 0 && H % 8 == 0 && W % 8 == 0, "pcc_codec_decode_main: block edges must be multiples of 8");
+    const int F = c->filters;
+    const size_t ny = (size_t)N * (D / 8) * (H / 8) * (W / 8) * F;
+    rc = pcc_dequantize(ctx, ysym, c->version == 1 ? c->medians : nullptr, y_hat, ny, F, stream);
+    if (rc != PCC_OK) return rc;
+    rc = pcc_network_forward(ctx, c->synthesis, F, c->w_synthesis, y_hat, N, D / 8, H / 8, W / 8, x_hat, workspace,
+                             workspace_bytes, layer_flags, 0, stream);
+    if (rc != PCC_OK || !thr) return rc;
+    PCC_REQUIRE(xyz && counts && scratch, "pcc_codec_decode_main: thr given but xyz / counts / scratch is NULL");
+    return pcc_threshold_compact(ctx, x_hat, N, D, H, W, thr, 0 /* the decoder does not clip, model_types.py:232-233 */, xyz, counts,
+                                 cap, scratch, stream);
+}

@@ -58,13 +58,13 @@ __global__ void __launch_bounds__(256) k_occupancy(const int* __restrict__ pts, 
 // 1-D squared distance along z (the contiguous axis) to the nearest voxel with level > t.
 // thread <-> (line (x,y), t); grid.z = block.  out: [b][t][x][y][z] uint16.
 __global__ void __launch_bounds__(256) k_edt_z(const unsigned char* __restrict__ lev, const int* __restrict__ tcount,
-                                               int tmax, int lines, int W, unsigned short* __restrict__ out) {
-    const int b = blockIdx.z, t = blockIdx.y;
+                                               int tmax, int t0, int lines, int W, unsigned short* __restrict__ out) {
+    const int b = blockIdx.z, tl = blockIdx.y, t = t0 + tl;      // tl: slot inside the resident chunk of `tmax` thresholds
     if (t >= tcount[b]) return;
     const int line = blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= lines) return;
     const unsigned char* l = lev + ((size_t)b * lines + line) * W;
-    unsigned short* o = out + (((size_t)b * tmax + t) * lines + line) * W;
+    unsigned short* o = out + (((size_t)b * tmax + tl) * lines + line) * W;
     int last = -100000;
     for (int z = 0; z < W; ++z) {           // forward sweep: distance to the previous set voxel
         if (l[z] > t) last = z;
@@ -83,12 +83,12 @@ __global__ void __launch_bounds__(256) k_edt_z(const unsigned char* __restrict__
 //   out[p] = min_{q on the same line} (p - q)^2 + in[q]
 // thread <-> one output element; innermost (contiguous) index fastest so that accesses stay coalesced.
 __global__ void __launch_bounds__(256) k_edt_axis(const unsigned short* __restrict__ in, const int* __restrict__ tcount,
-                                                  int tmax, size_t nvox, int L, int astride, unsigned short* __restrict__ out) {
-    const int b = blockIdx.z, t = blockIdx.y;
+                                                  int tmax, int t0, size_t nvox, int L, int astride, unsigned short* __restrict__ out) {
+    const int b = blockIdx.z, tl = blockIdx.y, t = t0 + tl;
     if (t >= tcount[b]) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nvox) return;
-    const size_t base = ((size_t)b * tmax + t) * nvox;
+    const size_t base = ((size_t)b * tmax + tl) * nvox;
     const int p = (int)((i / astride) % L);
     const unsigned short* c = in + base + i;
     unsigned best = c[0];
@@ -103,10 +103,10 @@ __global__ void __launch_bounds__(256) k_edt_axis(const unsigned short* __restri
 
 // last pass (along x = the slowest axis) evaluated only at the points of A: S_AB[b][t] += min_x' (x_a-x')^2 + g[x'][y_a][z_a]
 __global__ void __launch_bounds__(256) k_edt_points(const unsigned short* __restrict__ g, const int* __restrict__ tcount,
-                                                    int tmax, const int* __restrict__ pts, const int* __restrict__ block_of,
+                                                    int tmax, int t0, const int* __restrict__ pts, const int* __restrict__ block_of,
                                                     long long npts, int D, int H, int W,
                                                     unsigned long long* __restrict__ s_ab) {
-    const int t = blockIdx.y;
+    const int tl = blockIdx.y, t = t0 + tl;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long val = 0;
     int b = -1;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) k_edt_points(const unsigned short* __rest
         if (t < tcount[b]) {
             const int xa = pts[i * 3], ya = pts[i * 3 + 1], za = pts[i * 3 + 2];
             const size_t hw = (size_t)H * W;
-            const unsigned short* c = g + ((size_t)b * tmax + t) * D * hw + (size_t)ya * W + za;
+            const unsigned short* c = g + ((size_t)b * tmax + tl) * D * hw + (size_t)ya * W + za;
             unsigned best = c[(size_t)xa * hw];
             for (int d = 1; d < D; ++d) {
                 const unsigned dd = (unsigned)(d * d);
@@ -161,10 +161,20 @@ __global__ void __launch_bounds__(256) k_level_hist(const unsigned char* __restr
 
 }  // namespace
 
+// Thresholds resident at a time: the level-set EDTs are computed in chunks so that their two uint16 grids per
+// (block, threshold) stay within ~1 GiB (32 blocks of 64^3 -> 32 thresholds per chunk; 8 blocks of 128^3 -> 16).
+static int chunk_thresholds(int32_t B, size_t nvox) {
+    const size_t per_t = (size_t)B * nvox * 2 * 2;
+    size_t tc = ((size_t)1 << 30) / (per_t ? per_t : 1);
+    if (tc < 8) tc = 8;
+    if (tc > (size_t)kT) tc = kT;
+    return (int)tc;
+}
+
 PCC_API size_t pcc_d1_search_workspace_bytes(int32_t B, int32_t D, int32_t H, int32_t W) {
     const size_t nvox = (size_t)D * H * W;
-    // levels + occupancy (u8), EDT of A ping/pong (u16), level-set EDT ping/pong (u16 x 256), per-block counters
-    return (size_t)B * nvox * 2 + (size_t)B * nvox * 2 * 2 + (size_t)B * kT * nvox * 2 * 2 + (size_t)B * 64 + 4096;
+    // levels + occupancy (u8), EDT of A ping/pong (u16), level-set EDT ping/pong (u16 x chunk), per-block counters
+    return (size_t)B * nvox * 2 + (size_t)B * nvox * 2 * 2 + (size_t)B * chunk_thresholds(B, nvox) * nvox * 2 * 2 + (size_t)B * 64 + 4096;
 }
 
 // x_hat: (B,D,H,W) float32; thr: 256 float32 thresholds (device); pts: (npts,3) int32 local coordinates grouped by
@@ -188,8 +198,9 @@ PCC_API int pcc_d1_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, 
     unsigned short* ea0 = (unsigned short*)(occ + (size_t)B * nvox);
     unsigned short* ea1 = ea0 + (size_t)B * nvox;
     unsigned short* g0 = ea1 + (size_t)B * nvox;
-    unsigned short* g1 = g0 + (size_t)B * kT * nvox;
-    int* one = (int*)(g1 + (size_t)B * kT * nvox);   // per-block "1 threshold" counter for the EDT of A
+    const int TC = chunk_thresholds(B, nvox);
+    unsigned short* g1 = g0 + (size_t)B * TC * nvox;
+    int* one = (int*)(g1 + (size_t)B * TC * nvox);   // per-block "1 threshold" counter for the EDT of A
 
     PCC_CHECK_HIP(hipMemsetAsync(occ, 0, (size_t)B * nvox, st));
     PCC_CHECK_HIP(hipMemsetAsync(tcount, 0, (size_t)B * sizeof(int), st));
@@ -206,18 +217,22 @@ PCC_API int pcc_d1_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, 
         hipLaunchKernelGGL(k_occupancy, dim3(pblocks), dim3(256), 0, st, pts, block_of, (long long)npts, D, H, W, occ);
     }
     hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, one, 1, B);
-    hipLaunchKernelGGL(k_edt_z, dim3((lines + 255) / 256, 1, B), dim3(256), 0, st, occ, one, 1, lines, W, ea0);
-    hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, 1, B), dim3(256), 0, st, ea0, one, 1, nvox, H, W, ea1);
-    hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, 1, B), dim3(256), 0, st, ea1, one, 1, nvox, D, H * W, ea0);
+    hipLaunchKernelGGL(k_edt_z, dim3((lines + 255) / 256, 1, B), dim3(256), 0, st, occ, one, 1, 0, lines, W, ea0);
+    hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, 1, B), dim3(256), 0, st, ea0, one, 1, 0, nvox, H, W, ea1);
+    hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, 1, B), dim3(256), 0, st, ea1, one, 1, 0, nvox, D, H * W, ea0);
     hipLaunchKernelGGL(k_level_hist, dim3(64, B), dim3(256), 0, st, lev, ea0, nvox, (unsigned long long*)hsum,
                        (unsigned long long*)hcnt);
     // ---- EDT of every level set, evaluated at the points of A
-    hipLaunchKernelGGL(k_edt_z, dim3((lines + 255) / 256, nthr, B), dim3(256), 0, st, lev, tcount, kT, lines, W, g0);
-    hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, nthr, B), dim3(256), 0, st, g0, tcount, kT, nvox, H, W, g1);
-    if (npts > 0) {
-        const unsigned pblocks = (unsigned)((npts + 255) / 256);
-        hipLaunchKernelGGL(k_edt_points, dim3(pblocks, nthr), dim3(256), 0, st, g1, tcount, kT, pts, block_of,
-                           (long long)npts, D, H, W, (unsigned long long*)s_ab);
+    //      in chunks of TC thresholds (workspace bound); chunks beyond every block's tcount exit at once
+    for (int t0 = 0; t0 < nthr; t0 += TC) {
+        const int nt = nthr - t0 < TC ? nthr - t0 : TC;
+        hipLaunchKernelGGL(k_edt_z, dim3((lines + 255) / 256, nt, B), dim3(256), 0, st, lev, tcount, TC, t0, lines, W, g0);
+        hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, nt, B), dim3(256), 0, st, g0, tcount, TC, t0, nvox, H, W, g1);
+        if (npts > 0) {
+            const unsigned pblocks = (unsigned)((npts + 255) / 256);
+            hipLaunchKernelGGL(k_edt_points, dim3(pblocks, nt), dim3(256), 0, st, g1, tcount, TC, t0, pts, block_of,
+                               (long long)npts, D, H, W, (unsigned long long*)s_ab);
+        }
     }
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;

@@ -108,12 +108,41 @@ class Conv3DTranspose(_ConvBase):
 
 
 class SequentialLayer(Layer):
+    NET_ID = None        # PCC_NET_* id of the reference transform this class restates (set on the eight transforms)
+
     def __init__(self, layers, *args, **kwargs):
         self._layers = layers
         if layers:
             self.data_format = layers[0].data_format
+        self._net = None
+
+    @property
+    def net_filters(self):
+        # `filters` of the constructor = output channels of the last conv for the analysis / hyper transforms, input channels
+        # of the first conv for the synthesis transforms
+        convs = self.conv_layers()
+        return convs[-1].filters if convs[-1].filters > 1 else convs[0].layer.cin
+
+    def network(self):
+        """ops.NetworkWeights of this transform (rebuilt when a layer's weights were replaced), or None when the stack is
+        not the plain reference transform (no NET_ID, 'concat' residuals, a per-layer impl override, missing weights)."""
+        import os
+        if self.NET_ID is None or os.environ.get('PCC_LAYERWISE'):
+            return None
+        convs = self.conv_layers()
+        if any(c.layer is None or c.impl != L.PCC_IMPL_AUTO for c in convs):
+            return None
+        if any(isinstance(l, ResidualLayer) and l.residual_mode != 'add' for l in self._layers):
+            return None
+        key = tuple(id(c.layer) for c in convs)
+        if self._net is None or self._net[0] != key:
+            self._net = (key, ops.NetworkWeights(self.NET_ID, self.net_filters, [c.layer for c in convs]))
+        return self._net[1]
 
     def forward_ndhwc(self, ctx, x, final_flags=0):
+        net = self.network() if not (final_flags & ~L.PCC_CONV_CLIP01) else None
+        if net is not None:
+            return ops.network_forward(ctx, net, x, final_flags)       # the whole transform in one ABI call
         for i, layer in enumerate(self._layers):
             if final_flags and i == len(self._layers) - 1:
                 x = layer.forward_ndhwc(ctx, x, flags=final_flags)
@@ -153,6 +182,8 @@ class ResidualLayer(Layer):
 
 
 class AnalysisTransformV1(SequentialLayer):
+    NET_ID = L.PCC_NET_ANALYSIS_V1
+
     def __init__(self, filters, data_format=None, activation=relu, *args, **kwargs):
         data_format = normalize_data_format(data_format)
         params = {'strides': (2, 2, 2), 'padding': 'same', 'data_format': data_format, 'filters': filters}
@@ -163,6 +194,8 @@ class AnalysisTransformV1(SequentialLayer):
 
 
 class SynthesisTransformV1(SequentialLayer):
+    NET_ID = L.PCC_NET_SYNTHESIS_V1
+
     def __init__(self, filters, data_format=None, activation=relu, *args, **kwargs):
         data_format = normalize_data_format(data_format)
         params = {'strides': (2, 2, 2), 'padding': 'same', 'data_format': data_format, 'use_bias': True,
@@ -200,6 +233,8 @@ def _v2(block, first, out_layer, fs, data_format, kernel_size, activation, resid
 
 
 class AnalysisTransformV2(SequentialLayer):
+    NET_ID = L.PCC_NET_ANALYSIS_V2
+
     def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), activation=relu, residual_mode='add',
                  *args, **kwargs):
         data_format = normalize_data_format(data_format)
@@ -209,6 +244,8 @@ class AnalysisTransformV2(SequentialLayer):
 
 
 class SynthesisTransformV2(SequentialLayer):
+    NET_ID = L.PCC_NET_SYNTHESIS_V2
+
     def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), activation=relu, residual_mode='add',
                  *args, **kwargs):
         data_format = normalize_data_format(data_format)
@@ -219,6 +256,8 @@ class SynthesisTransformV2(SequentialLayer):
 
 
 class AnalysisTransformProgressiveV2(SequentialLayer):
+    NET_ID = L.PCC_NET_ANALYSIS_PROGRESSIVE_V2
+
     def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), activation=relu, residual_mode='add',
                  *args, **kwargs):
         data_format = normalize_data_format(data_format)
@@ -228,6 +267,8 @@ class AnalysisTransformProgressiveV2(SequentialLayer):
 
 
 class SynthesisTransformProgressiveV2(SequentialLayer):
+    NET_ID = L.PCC_NET_SYNTHESIS_PROGRESSIVE_V2
+
     def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), activation=relu, residual_mode='add',
                  *args, **kwargs):
         data_format = normalize_data_format(data_format)
@@ -238,6 +279,8 @@ class SynthesisTransformProgressiveV2(SequentialLayer):
 
 
 class HyperAnalysisTransform(SequentialLayer):
+    NET_ID = L.PCC_NET_HYPER_ANALYSIS
+
     def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), activation=relu, *args, **kwargs):
         data_format = normalize_data_format(data_format)
         params = {'padding': 'same', 'data_format': data_format, 'filters': filters, 'kernel_size': kernel_size}
@@ -248,6 +291,8 @@ class HyperAnalysisTransform(SequentialLayer):
 
 
 class HyperSynthesisTransform(SequentialLayer):
+    NET_ID = L.PCC_NET_HYPER_SYNTHESIS
+
     def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), activation=relu, *args, **kwargs):
         data_format = normalize_data_format(data_format)
         params = {'padding': 'same', 'data_format': data_format, 'activation': activation, 'use_bias': True,

@@ -138,16 +138,20 @@ class CompressionModel:
             self._copy_stream = torch.cuda.Stream(ctx.device)
         return self._copy_stream
 
-    def _copy_out(self, ctx, pairs):
-        """Device->pinned-host copies on a side stream; returns the event the host has to wait for."""
+    def _copy_out(self, ctx, pairs, ready=None):
+        """Device->pinned-host copies (after the permutation into stream order) on a side stream; returns the event the host
+        has to wait for.  `ready`: event after which the sources are final (default: now, on the main stream)."""
         main = torch.cuda.current_stream(ctx.device)
         if not hasattr(self, '_copy_stream'):
             self._copy_stream = torch.cuda.Stream(ctx.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
+        if ready is None:
+            ready = torch.cuda.Event()
+            ready.record(main)
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(ready)
             for dst, src in pairs:
+                src.record_stream(self._copy_stream)
+                src = self._to_stream_order(src)
                 dst.copy_(src, non_blocking=True)
                 src.record_stream(self._copy_stream)
             done = torch.cuda.Event()
@@ -193,8 +197,8 @@ class CompressionModel:
         bof = np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(blocks)])
         return ops.voxelize(ctx, torch.from_numpy(pts).to(ctx.device), torch.from_numpy(bof).to(ctx.device), B, D, H, W)
 
-    def _extract_points(self, ctx, x_hat, thr_idx, clip):
-        """x_hat (B,D,H,W) device; thr_idx list of ints -> list of (n,3) float32 numpy arrays."""
+    def _thr_tensor(self, ctx, thr_idx):
+        """float32 thresholds of the blocks of a chunk as a device tensor."""
         # cached on the device: a pageable host->device copy here would block the host until the GPU drains
         # and serialise the pipeline
         thr_idx = [int(t) for t in thr_idx]
@@ -203,8 +207,27 @@ class CompressionModel:
         else:                          # adaptive thresholds vary per chunk: gather from the cached 256-entry table
             table = self._dev(ctx, 'thr_table', np.array([self._thr32(t) for t in range(len(self.thresholds))], np.float32))
             thr = table[torch.tensor(thr_idx, dtype=torch.int64).to(ctx.device, non_blocking=True)]
-        xyz, counts = ops.threshold_compact(ctx, x_hat, thr, clip=clip)
-        return xyz, counts
+        return thr
+
+    def _extract_points(self, ctx, x_hat, thr_idx, clip):
+        """x_hat (B,D,H,W) device; thr_idx list of ints -> (xyz (B,cap,3), counts (B,)) device tensors."""
+        return ops.threshold_compact(ctx, x_hat, self._thr_tensor(ctx, thr_idx), clip=clip)
+
+    def _codec(self, ctx):
+        """pcc_codec_desc of this model on ctx's GPU (the batched-graph ABI), or None when a transform is not one of the
+        plain reference stacks (then the per-layer path is used)."""
+        nets = {}
+        for prefix, tr, _ in self._transforms():
+            nets[prefix] = tr.network() if hasattr(tr, 'network') else None
+            if nets[prefix] is None:
+                return None
+        key = (ctx.device.index,) + tuple(id(n) for n in nets.values())
+        if getattr(self, '_codec_cache', (None,))[0] != key:
+            v2 = isinstance(self, CompressionModelV2)
+            med = self._dev(ctx, 'medians', self.entropy_bottleneck.medians)
+            tab = self._dev(ctx, 'scale_table', self.conditional_bottleneck.scale_table_f32) if v2 else None
+            self._codec_cache = (key, ops.codec_desc(ctx, 2 if v2 else 1, self.num_filters, nets, med, tab, self.round_mode))
+        return self._codec_cache[1][0]
 
     def _gather_points(self, xyz, counts, ctx=None, ready=None):
         """Point lists to the host.  When `ready` (an event recorded after the compaction kernels) is given, the
@@ -286,12 +309,12 @@ class CompressionModel:
         for c0 in range(0, len(blocks), self.batch_size):
             chunk = blocks[c0:c0 + self.batch_size]
             x = self._voxelize(ctx, chunk, dhw)
-            enc = self._encode_batch(ctx, x, debug)
+            enc = self._encode_batch(ctx, x, debug, thr=self._thr_tensor(ctx, [half] * len(chunk)) if fixed_threshold else None)
             x_hat = enc['x_hat']
             if fixed_threshold:
                 # compute_optimal_thresholds' fixed branch (model_opt.py:27-31): index len//2 for every metric
                 n_m = len(max_deltas) * len(opt_metrics)
-                xyz, counts = self._extract_points(ctx, x_hat, [half] * len(chunk), clip=True)
+                xyz, counts = enc['xyz'], enc['counts']
                 strings = enc['finish']()
                 pts = self._gather_points(xyz, counts)
                 for j in range(len(chunk)):
@@ -431,8 +454,8 @@ class CompressionModel:
 
         def stage_b(item):
             strings, cnt_e, st, dhw, B = item
-            dec = self._decode_phase_b(ctx, st, dhw, False)
-            xyz_d, cnt_d = self._extract_points(ctx, dec['x_hat'], [thr_idx] * B, clip=False)
+            dec = self._decode_phase_b(ctx, st, dhw, False, thr=self._thr_tensor(ctx, [thr_idx] * B))
+            xyz_d, cnt_d = dec['xyz'], dec['counts']
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(ctx.device))
             return strings, cnt_e, xyz_d, cnt_d, ready
@@ -451,8 +474,8 @@ class CompressionModel:
 
         for x in dense_chunks:
             B, dhw = x.shape[0], tuple(x.shape[1:4])
-            enc = self._encode_batch(ctx, x, False)
-            _, cnt_e = self._extract_points(ctx, enc['x_hat'], [thr_idx] * B, clip=True)
+            enc = self._encode_batch(ctx, x, False, thr=self._thr_tensor(ctx, [thr_idx] * B))
+            cnt_e = enc['counts']
             strings = enc['finish']()
             st = self._decode_phase_a(ctx, strings, dhw)
             q_b.append((strings, cnt_e, st, dhw, B))
@@ -494,9 +517,9 @@ class CompressionModel:
             if k < len(chunks):
                 state[k] = self._decode_phase_a(ctx, [s for s, _ in chunks[k]], dhw)
             if k >= 1:
-                dec = self._decode_phase_b(ctx, state[k - 1], dhw, debug)
                 thr_idx = [int(t) for _, t in chunks[k - 1]]
-                xyz, counts = self._extract_points(ctx, dec['x_hat'], thr_idx, clip=False)  # decoder does not clip (:232-233)
+                dec = self._decode_phase_b(ctx, state[k - 1], dhw, debug, thr=self._thr_tensor(ctx, thr_idx))
+                xyz, counts = dec['xyz'], dec['counts']                 # the decoder does not clip (:232-233)
                 results[k - 1] = (xyz, counts, dec['debug'])
                 state[k - 1] = None
         dec_blocks, debug_t_list = [], []
@@ -561,16 +584,27 @@ class CompressionModelV1(CompressionModel):
         self.init_weights()
 
     # ---- batched graph
-    def _encode_batch(self, ctx, x, debug):
+    def _encode_batch(self, ctx, x, debug, thr=None):
         B = x.shape[0]
         eb = self.entropy_bottleneck
-        med = self._dev(ctx, 'medians', eb.medians)
-        y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
-        ysym, y_hat = ops.quantize(ctx, y, med, self.round_mode)
-        ysym_s = self._to_stream_order(ysym)
-        ysym_h = self._pinned.get('ysym', ysym_s.shape, torch.int32)
-        ev = self._copy_out(ctx, [(ysym_h, ysym_s)])
-        x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+        codec = self._codec(ctx)
+        t = {}
+        ready = None
+        if codec is not None:                      # analysis -> quantise -> synthesis (-> fixed threshold) in one ABI call
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(ctx.device))      # creates the handle; re-recorded by the library
+            t = ops.codec_encode(ctx, codec, x.contiguous(), thr, symbols_ready=ready)
+            y, ysym, y_hat, x_hat = t['y'], t['symbols'], t['y_hat'], t['x_hat']
+        else:
+            med = self._dev(ctx, 'medians', eb.medians)
+            y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
+            ysym, y_hat = ops.quantize(ctx, y, med, self.round_mode)
+        ysym_h = self._pinned.get('ysym', self._stream_shape(B, ysym.shape[1:4], self.num_filters), torch.int32)
+        ev = self._copy_out(ctx, [(ysym_h, ysym)], ready)
+        if codec is None:
+            x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
+            if thr is not None:
+                t['xyz'], t['counts'] = ops.threshold_compact(ctx, x_hat, thr, clip=True)
         rows, mod = self._eb_rows(ysym[0].numel(), self.num_filters)
 
         def finish():
@@ -581,7 +615,7 @@ class CompressionModelV1(CompressionModel):
 
         dbg = [{'y': _np(y[b:b + 1]), 'symbols': _np(ysym[b:b + 1]), 'y_hat': _np(y_hat[b:b + 1]),
                 'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))} for b in range(B)] if debug else [None] * B
-        return dict(x_hat=x_hat, finish=finish, debug=dbg)
+        return dict(x_hat=x_hat, finish=finish, debug=dbg, xyz=t.get('xyz'), counts=t.get('counts'))
 
     def _decode_phase_a(self, ctx, strings, dhw):
         B = len(strings)
@@ -594,15 +628,22 @@ class CompressionModelV1(CompressionModel):
                                self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
         return dict(ysym_h=ysym_h)
 
-    def _decode_phase_b(self, ctx, st, dhw, debug):
+    def _decode_phase_b(self, ctx, st, dhw, debug, thr=None):
         eb = self.entropy_bottleneck
-        med = self._dev(ctx, 'medians', eb.medians)
         ysym = self._from_stream_order(st['ysym_h'].to(ctx.device, non_blocking=True))
-        y_hat = ops.dequantize(ctx, ysym, med)
-        x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+        codec = self._codec(ctx)
+        if codec is not None:                      # dequantise -> synthesis (-> threshold + compaction) in one ABI call
+            t = ops.codec_decode_main(ctx, codec, ysym, dhw, thr)
+            y_hat, x_hat = t['y_hat'], t['x_hat']
+        else:
+            y_hat = ops.dequantize(ctx, ysym, self._dev(ctx, 'medians', eb.medians))
+            x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
+            t = {}
+            if thr is not None:
+                t['xyz'], t['counts'] = ops.threshold_compact(ctx, x_hat, thr, clip=False)
         B = x_hat.shape[0]
         dbg = [{'y_hat': _np(y_hat[b:b + 1]), 'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))} for b in range(B)] if debug else [None] * B
-        return dict(x_hat=x_hat.contiguous(), debug=dbg)
+        return dict(x_hat=x_hat, debug=dbg, xyz=t.get('xyz'), counts=t.get('counts'))
 
 
 class CompressionModelV2(CompressionModel):
@@ -670,29 +711,42 @@ class CompressionModelV2(CompressionModel):
         self.init_weights()
 
     # ---- batched graph: x -A-> y -HA-> z -EB-> z_string ; z_hat -HS-> sigma ; (y, sigma) -GC-> y_string ; y_hat -S-> x_hat
-    def _encode_batch(self, ctx, x, debug):
+    def _encode_batch(self, ctx, x, debug, thr=None):
         B = x.shape[0]
         F = self.num_filters
         eb, gc = self.entropy_bottleneck, self.conditional_bottleneck
-        med = self._dev(ctx, 'medians', eb.medians)
-        tab = self._dev(ctx, 'scale_table', gc.scale_table_f32)
-        y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
-        z = self.hyper_analysis_transform.forward_ndhwc(ctx, y)
-        zsym, z_hat = ops.quantize(ctx, z, med, self.round_mode)
-        sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
-        idx = ops.scale_to_index(ctx, sigma, tab)
-        ysym, y_hat = ops.quantize(ctx, y, None, self.round_mode)
-        zsym_s, ysym_s, idx_s = self._to_stream_order(zsym), self._to_stream_order(ysym), self._to_stream_order(idx)
-        zsym_h = self._pinned.get('zsym', zsym_s.shape, torch.int32)
-        ysym_h = self._pinned.get('ysym', ysym_s.shape, torch.int32)
-        idx_h = self._pinned.get('idx', idx_s.shape, torch.int32)
-        # symbols leave on a side stream so that the copies overlap the synthesis transform
-        ev = self._copy_out(ctx, [(zsym_h, zsym_s), (ysym_h, ysym_s), (idx_h, idx_s)])
-        x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+        codec = self._codec(ctx)
+        t = {}
+        ready = None
+        if codec is not None:                      # the whole GPU part of compress() (model_types.py:379-388) in one ABI call
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(ctx.device))      # creates the handle; re-recorded by the library
+            t = ops.codec_encode(ctx, codec, x.contiguous(), thr, symbols_ready=ready)
+            y, z, zsym, z_hat, sigma, idx, ysym, y_hat, x_hat = (t[k] for k in ('y', 'z', 'z_symbols', 'z_hat', 'sigma_hat',
+                                                                                'indexes', 'symbols', 'y_hat', 'x_hat'))
+        else:
+            med = self._dev(ctx, 'medians', eb.medians)
+            tab = self._dev(ctx, 'scale_table', gc.scale_table_f32)
+            y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
+            z = self.hyper_analysis_transform.forward_ndhwc(ctx, y)
+            zsym, z_hat = ops.quantize(ctx, z, med, self.round_mode)
+            sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
+            idx = ops.scale_to_index(ctx, sigma, tab)
+            ysym, y_hat = ops.quantize(ctx, y, None, self.round_mode)
+        zsym_h = self._pinned.get('zsym', self._stream_shape(B, zsym.shape[1:4], F), torch.int32)
+        ysym_h = self._pinned.get('ysym', self._stream_shape(B, ysym.shape[1:4], F), torch.int32)
+        idx_h = self._pinned.get('idx', self._stream_shape(B, idx.shape[1:4], F), torch.int32)
+        # symbols leave on a side stream (permutation into stream order + copy) so that they overlap the synthesis transform:
+        # `ready` is recorded by the library between the last quantiser and the first synthesis layer
+        ev = self._copy_out(ctx, [(zsym_h, zsym), (ysym_h, ysym), (idx_h, idx)], ready)
+        if codec is None:
+            x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
+            if thr is not None:
+                t['xyz'], t['counts'] = ops.threshold_compact(ctx, x_hat, thr, clip=True)
         rows, mod = self._eb_rows(zsym[0].numel(), F)
 
         def finish():
-            ev.synchronize()  # symbols are on the host; the synthesis transform is still running on the GPU
+            ev.synchronize()  # symbols are on the host
             zs = ops.range_encode_batch(eb.table, [zsym_h[b] for b in range(B)], None if rows is None else [rows] * B, mod,
                                         self.coder_threads)
             ys = ops.range_encode_batch(gc.table, [ysym_h[b] for b in range(B)], [idx_h[b] for b in range(B)], 0,
@@ -705,23 +759,27 @@ class CompressionModelV2(CompressionModel):
                     'z_hat': _np(z_hat[b:b + 1]), 'sigma_hat': _np(sigma[b:b + 1]), 'indexes': _np(idx[b:b + 1]),
                     'symbols': _np(ysym[b:b + 1]), 'y_hat': _np(y_hat[b:b + 1]), 'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))}
                    for b in range(B)]
-        return dict(x_hat=x_hat, finish=finish, debug=dbg)
+        return dict(x_hat=x_hat, finish=finish, debug=dbg, xyz=t.get('xyz'), counts=t.get('counts'))
 
     def _decode_phase_a(self, ctx, strings, dhw):
         """z_string -EB.decompress-> z_hat -HS-> sigma -> indexes (async D2H)."""
         B, F = len(strings), self.num_filters
         eb, gc = self.entropy_bottleneck, self.conditional_bottleneck
-        med = self._dev(ctx, 'medians', eb.medians)
-        tab = self._dev(ctx, 'scale_table', gc.scale_table_f32)
         zshape = self._stream_shape(B, [v // 16 for v in dhw], F)
         zsym_h = torch.empty(zshape, dtype=torch.int32, pin_memory=True)
         nz = int(np.prod(zshape[1:]))
         rows, mod = self._eb_rows(nz, F)
         ops.range_decode_batch(eb.table, [s[1] for s in strings], [nz] * B, None if rows is None else [rows] * B, mod,
                                self.coder_threads, out=[zsym_h[b].numpy() for b in range(B)])
-        z_hat = ops.dequantize(ctx, self._from_stream_order(zsym_h.to(ctx.device, non_blocking=True)), med)
-        sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
-        idx = ops.scale_to_index(ctx, sigma, tab)
+        zsym = self._from_stream_order(zsym_h.to(ctx.device, non_blocking=True))
+        codec = self._codec(ctx)
+        if codec is not None:                      # dequantise z -> hyper-synthesis -> indexes in one ABI call
+            t = ops.codec_decode_hyper(ctx, codec, zsym, dhw)
+            z_hat, sigma, idx = t['z_hat'], t['sigma_hat'], t['indexes']
+        else:
+            z_hat = ops.dequantize(ctx, zsym, self._dev(ctx, 'medians', eb.medians))
+            sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
+            idx = ops.scale_to_index(ctx, sigma, self._dev(ctx, 'scale_table', gc.scale_table_f32))
         idx_s = self._to_stream_order(idx)
         idx_h = torch.empty(idx_s.shape, dtype=torch.int32, pin_memory=True)
         idx_h.copy_(idx_s, non_blocking=True)
@@ -729,8 +787,8 @@ class CompressionModelV2(CompressionModel):
         ev.record(torch.cuda.current_stream(ctx.device))
         return dict(strings=strings, idx_h=idx_h, ev=ev, z_hat=z_hat, sigma=sigma, idx=idx, zsym_h=zsym_h)
 
-    def _decode_phase_b(self, ctx, st, dhw, debug):
-        """(y_string, indexes) -GC.decompress-> y_hat -S-> x_hat."""
+    def _decode_phase_b(self, ctx, st, dhw, debug, thr=None):
+        """(y_string, indexes) -GC.decompress-> y_hat -S-> x_hat [-> thresholded points]."""
         gc = self.conditional_bottleneck
         strings, idx_h = st['strings'], st['idx_h']
         B = len(strings)
@@ -740,14 +798,22 @@ class CompressionModelV2(CompressionModel):
         ops.range_decode_batch(gc.table, [s[0] for s in strings], [n] * B, [idx_h[b] for b in range(B)], 0,
                                self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
         ysym = self._from_stream_order(ysym_h.to(ctx.device, non_blocking=True))
-        y_hat = ops.dequantize(ctx, ysym, None)
-        x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0]
+        codec = self._codec(ctx)
+        if codec is not None:                      # dequantise -> synthesis (-> threshold + compaction) in one ABI call
+            t = ops.codec_decode_main(ctx, codec, ysym, dhw, thr)
+            y_hat, x_hat = t['y_hat'], t['x_hat']
+        else:
+            y_hat = ops.dequantize(ctx, ysym, None)
+            x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
+            t = {}
+            if thr is not None:
+                t['xyz'], t['counts'] = ops.threshold_compact(ctx, x_hat, thr, clip=False)
         dbg = [None] * B
         if debug:
             dbg = [{'z_hat': _np(st['z_hat'][b:b + 1]), 'sigma_hat': _np(st['sigma'][b:b + 1]),
                     'indexes': _np(st['idx'][b:b + 1]), 'symbols': _np(ysym[b:b + 1]), 'y_hat': _np(y_hat[b:b + 1]),
                     'x_hat': _np(x_hat[b:b + 1].unsqueeze(-1))} for b in range(B)]
-        return dict(x_hat=x_hat.contiguous(), debug=dbg)
+        return dict(x_hat=x_hat, debug=dbg, xyz=t.get('xyz'), counts=t.get('counts'))
 
 
 class ModelType(Enum):

@@ -31,6 +31,14 @@ class Context:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def workspace(self, nbytes):
+        """Activations workspace of the batched-graph entry points: one caller-owned device buffer per context, grown on
+        demand.  Calls on a context are ordered on one stream, so consecutive transforms may reuse it."""
+        ws = getattr(self, '_ws', None)
+        if ws is None or ws.numel() < nbytes:
+            self._ws = ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
+        return ws
+
     def close(self):
         if self.handle is not None:
             L.lib().pcc_ctx_destroy(self.handle)
@@ -141,6 +149,153 @@ def conv3d(ctx, x, layer, residual=None, flags=0, impl=L.PCC_IMPL_AUTO, out=None
         e1.record(torch.cuda.current_stream(ctx.device))
         PROFILE['events'].append((e0, e1))
     return out
+
+
+class NetworkWeights:
+    """The weights of one whole transform (src/model_transforms.py:41-158) as ONE packed device blob per GPU
+    (pcc_weights_upload): Keras-layout kernel + MFMA/Winograd fragment image + bias of every conv layer."""
+
+    def __init__(self, transform_id, filters, conv_layers):
+        self.transform, self.filters = int(transform_id), int(filters)
+        n = L.lib().pcc_network_num_layers(self.transform, self.filters)
+        L.check(n, 'pcc_network_num_layers')
+        assert n == len(conv_layers), f'transform {transform_id}: {n} layers in the library, {len(conv_layers)} in the model'
+        d, role = L.ConvDesc(), C.c_int32()
+        for i, cl in enumerate(conv_layers):     # the model's layers must be the reference stack the library restates
+            L.check(L.lib().pcc_network_layer(self.transform, self.filters, i, C.byref(d), C.byref(role)), 'pcc_network_layer')
+            got = (cl.cin, cl.cout, cl.k, cl.stride, int(cl.transposed), cl.bias is not None, cl.relu)
+            want = (d.Cin, d.Cout, d.k, d.stride, d.transposed, bool(d.flags & L.PCC_CONV_BIAS), bool(d.flags & L.PCC_CONV_RELU))
+            assert got == want, f'layer {i} of transform {transform_id}: model {got} != library {want}'
+        self.layers = list(conv_layers)
+        self._blob = {}
+
+    def blob(self, ctx):
+        key = ctx.device.index
+        if key not in self._blob:
+            n = len(self.layers)
+            ks = (C.c_void_p * n)(*[l.kernel.ctypes.data for l in self.layers])
+            bs = (C.c_void_p * n)(*[None if l.bias is None else l.bias.ctypes.data for l in self.layers])
+            dev = torch.empty((L.lib().pcc_weights_blob_floats(self.transform, self.filters),), dtype=torch.float32, device=ctx.device)
+            L.check(L.lib().pcc_weights_upload(ctx.handle, self.transform, self.filters, ks, bs, _ptr(dev), ctx.stream),
+                    'pcc_weights_upload')
+            self._blob[key] = dev
+        return self._blob[key]
+
+
+_FAMILY = {0: 'analysis', 2: 'analysis', 4: 'analysis', 1: 'synthesis', 3: 'synthesis', 5: 'synthesis', 6: 'hyper_a', 7: 'hyper_s'}
+
+
+def network_forward(ctx, net, x, final_flags=0):
+    """y = transform(x) in ONE ABI call (pcc_network_forward_{analysis,synthesis,hyper_a,hyper_s}).  x: (N,D,H,W,Cin)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.device == ctx.device and x.dim() == 5
+    N, D, H, W, _ = x.shape
+    od, oh, ow, oc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    L.check(L.lib().pcc_network_out_dims(net.transform, net.filters, D, H, W, C.byref(od), C.byref(oh), C.byref(ow), C.byref(oc)),
+            'pcc_network_out_dims')
+    y = torch.empty((N, od.value, oh.value, ow.value, oc.value), dtype=torch.float32, device=ctx.device)
+    nb = L.lib().pcc_network_workspace_bytes(net.transform, net.filters, N, D, H, W)
+    ws = ctx.workspace(nb)
+    fn = getattr(L.lib(), 'pcc_network_forward_' + _FAMILY[net.transform])
+    L.check(fn(ctx.handle, net.transform, net.filters, _ptr(net.blob(ctx)), _ptr(x), N, D, H, W, _ptr(y), _ptr(ws), ws.numel(),
+               getattr(ctx, 'conv_flags', 0), final_flags, ctx.stream), 'pcc_network_forward')
+    return y
+
+
+def codec_desc(ctx, version, filters, nets, medians=None, scale_table=None, round_mode=L.PCC_ROUND_FLOOR_HALF):
+    """pcc_codec_desc of a model: nets = dict(analysis=, synthesis=, hyper_analysis=, hyper_synthesis=) of NetworkWeights
+    (None where absent); medians / scale_table: device tensors.  Returns (desc, keepalive)."""
+    d = L.CodecDesc()
+    d.version, d.filters, d.round_mode = version, filters, round_mode
+    d.analysis = nets['analysis'].transform if nets.get('analysis') is not None else -1
+    d.synthesis = nets['synthesis'].transform
+    keep = []
+    for name in ('analysis', 'synthesis', 'hyper_analysis', 'hyper_synthesis'):
+        net = nets.get(name)
+        blob = net.blob(ctx) if net is not None else None
+        keep.append(blob)
+        setattr(d, 'w_' + name, None if blob is None else blob.data_ptr())
+    d.medians = None if medians is None else medians.data_ptr()
+    d.scale_table = None if scale_table is None else scale_table.data_ptr()
+    d.scale_levels = 0 if scale_table is None else scale_table.numel()
+    keep += [medians, scale_table]
+    return d, keep
+
+
+def codec_encode(ctx, desc, x, thr=None, cap=None, symbols_ready=None):
+    """The GPU part of compress() (src/model_types.py:289-293 / :379-388) for a batch of blocks in ONE ABI call.
+    x: (N,D,H,W) float32.  Returns dict of device tensors (NDHWC); with `thr` (N,) float32 also the encoder-side point
+    lists xyz / counts of the clipped x_hat (fixed-threshold policy).  symbols_ready: a torch.cuda.Event that has been
+    recorded once (so that its handle exists); the library re-records it when the symbols are final."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.device == ctx.device
+    N, D, H, W = x.shape
+    F, dev = desc.filters, ctx.device
+    f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    i32 = lambda *sh: torch.empty(sh, dtype=torch.int32, device=dev)
+    ys, zs = (N, D // 8, H // 8, W // 8, F), (N, D // 16, H // 16, W // 16, F)
+    t = dict(y=f32(*ys), symbols=i32(*ys), y_hat=f32(*ys), x_hat=f32(N, D, H, W))
+    if desc.version == 2:
+        t.update(z=f32(*zs), z_symbols=i32(*zs), z_hat=f32(*zs), sigma_hat=f32(*ys), indexes=i32(*ys))
+    xyz = counts = scratch = None
+    cap = D * H * W if cap is None else int(cap)
+    if thr is not None:
+        assert thr.dtype == torch.float32 and thr.numel() == N
+        xyz, counts = torch.empty((N, cap, 3), dtype=torch.float32, device=dev), torch.empty((N,), dtype=torch.int32, device=dev)
+        scratch = torch.empty((L.lib().pcc_threshold_scratch_ints(N, D, H, W),), dtype=torch.int32, device=dev)
+        t.update(xyz=xyz, counts=counts)
+    ws = ctx.workspace(L.lib().pcc_codec_workspace_bytes(C.byref(desc), N, D, H, W))
+    L.check(L.lib().pcc_codec_encode(ctx.handle, C.byref(desc), _ptr(x), N, D, H, W, _ptr(t['y']), _ptr(t.get('z')),
+                                     _ptr(t.get('z_symbols')), _ptr(t.get('z_hat')), _ptr(t.get('sigma_hat')),
+                                     _ptr(t.get('indexes')), _ptr(t['symbols']), _ptr(t['y_hat']), _ptr(t['x_hat']), _ptr(thr),
+                                     _ptr(xyz), _ptr(counts), cap, _ptr(scratch), _ptr(ws), ws.numel(),
+                                     getattr(ctx, 'conv_flags', 0), 0,
+                                     None if symbols_ready is None else C.c_void_p(symbols_ready.cuda_event), ctx.stream),
+            'pcc_codec_encode')
+    return t
+
+
+def codec_decode_hyper(ctx, desc, zsym, dhw):
+    """z symbols (N,D/16,H/16,W/16,F) int32 -> z_hat, sigma_hat, indexes (src/model_types.py:403-406), one ABI call."""
+    N, (D, H, W), F, dev = zsym.shape[0], dhw, desc.filters, ctx.device
+    assert zsym.dtype == torch.int32 and zsym.is_contiguous() and tuple(zsym.shape) == (N, D // 16, H // 16, W // 16, F)
+    ys = (N, D // 8, H // 8, W // 8, F)
+    t = dict(z_hat=torch.empty(zsym.shape, dtype=torch.float32, device=dev), sigma_hat=torch.empty(ys, dtype=torch.float32, device=dev),
+             indexes=torch.empty(ys, dtype=torch.int32, device=dev))
+    ws = ctx.workspace(L.lib().pcc_codec_workspace_bytes(C.byref(desc), N, D, H, W))
+    L.check(L.lib().pcc_codec_decode_hyper(ctx.handle, C.byref(desc), _ptr(zsym), N, D, H, W, _ptr(t['z_hat']), _ptr(t['sigma_hat']),
+                                           _ptr(t['indexes']), _ptr(ws), ws.numel(), getattr(ctx, 'conv_flags', 0), ctx.stream),
+            'pcc_codec_decode_hyper')
+    return t
+
+
+def codec_decode_main(ctx, desc, ysym, dhw, thr=None, cap=None):
+    """y symbols -> y_hat -> x_hat (+ thresholding and compaction when `thr` (N,) float32 is given), one ABI call
+    (src/model_types.py:305-307 / :407-408, :232-234)."""
+    N, (D, H, W), F, dev = ysym.shape[0], dhw, desc.filters, ctx.device
+    assert ysym.dtype == torch.int32 and ysym.is_contiguous() and tuple(ysym.shape) == (N, D // 8, H // 8, W // 8, F)
+    t = dict(y_hat=torch.empty(ysym.shape, dtype=torch.float32, device=dev), x_hat=torch.empty((N, D, H, W), dtype=torch.float32, device=dev))
+    xyz = counts = scratch = None
+    cap = D * H * W if cap is None else int(cap)
+    if thr is not None:
+        assert thr.dtype == torch.float32 and thr.numel() == N
+        xyz = torch.empty((N, cap, 3), dtype=torch.float32, device=dev)
+        counts = torch.empty((N,), dtype=torch.int32, device=dev)
+        scratch = torch.empty((L.lib().pcc_threshold_scratch_ints(N, D, H, W),), dtype=torch.int32, device=dev)
+        t.update(xyz=xyz, counts=counts)
+    ws = ctx.workspace(L.lib().pcc_codec_workspace_bytes(C.byref(desc), N, D, H, W))
+    L.check(L.lib().pcc_codec_decode_main(ctx.handle, C.byref(desc), _ptr(ysym), N, D, H, W, _ptr(t['y_hat']), _ptr(t['x_hat']),
+                                          _ptr(thr), _ptr(xyz), _ptr(counts), cap, _ptr(scratch), _ptr(ws), ws.numel(),
+                                          getattr(ctx, 'conv_flags', 0), ctx.stream), 'pcc_codec_decode_main')
+    return t
+
+
+def profile_select(ctx, transform, layer):
+    L.check(L.lib().pcc_profile_select(ctx.handle, transform, layer), 'pcc_profile_select')
+
+
+def profile_read(ctx, cap=8192):
+    ms, n = (C.c_float * cap)(), C.c_int32()
+    L.check(L.lib().pcc_profile_read(ctx.handle, ms, cap, C.byref(n)), 'pcc_profile_read')
+    return [ms[i] for i in range(n.value)]
 
 
 def mfma_supported(layer, x_shape):

@@ -21,7 +21,58 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f'symbols declared in pcc_geo.h but not exported: {missing}'
     assert set(L.EXPORTS) <= declared
-    assert L.lib().pcc_abi_version() == 1
+    assert L.lib().pcc_abi_version() == L.ABI_VERSION == 2
+
+
+def test_network_layer_tables_match_the_oracle_restatement(oracle):
+    """The C++ layer stacks behind pcc_network_forward (csrc/network.hip) against the oracle's independent restatement of
+    /root/reference/src/model_transforms.py:41-158, and the packed weight blob against the per-layer packer (host only)."""
+    names = ['AnalysisTransformV1', 'SynthesisTransformV1', 'AnalysisTransformV2', 'SynthesisTransformV2',
+             'AnalysisTransformProgressiveV2', 'SynthesisTransformProgressiveV2', 'HyperAnalysisTransform', 'HyperSynthesisTransform']
+    lib = L.lib()
+    rng = np.random.default_rng(0)
+    for tid, name in enumerate(names):
+        F = 64 if 'Progressive' in name or 'Hyper' in name else 32
+        ref = oracle.transform_layers(name, F)
+        assert lib.pcc_network_num_layers(tid, F) == len(ref)
+        cin = 1 if name.startswith('Analysis') else F
+        d, role = L.ConvDesc(), C.c_int32()
+        kernels, biases = [], []
+        for i, (kind, cout, k, s, bias, relu, res) in enumerate(ref):
+            assert lib.pcc_network_layer(tid, F, i, C.byref(d), C.byref(role)) == 0
+            assert (d.Cin, d.Cout, d.k, d.stride, d.transposed) == (cin, cout, k, s, int(kind == 'convT')), (name, i)
+            assert bool(d.flags & L.PCC_CONV_BIAS) == bias and bool(d.flags & L.PCC_CONV_RELU) == relu
+            assert role.value == {None: 0, 'save': 1, 'add': 2}[res]
+            shape = (k, k, k, cout, cin) if kind == 'convT' else (k, k, k, cin, cout)
+            kernels.append(rng.standard_normal(shape).astype(np.float32))
+            biases.append(rng.standard_normal(cout).astype(np.float32) if bias else None)
+            cin = cout
+        n = lib.pcc_weights_blob_floats(tid, F)
+        blob = np.full(n, np.nan, np.float32)
+        ks = (C.c_void_p * len(ref))(*[a.ctypes.data for a in kernels])
+        bs = (C.c_void_p * len(ref))(*[None if b is None else b.ctypes.data for b in biases])
+        assert lib.pcc_weights_pack(tid, F, ks, bs, blob.ctypes.data_as(C.c_void_p)) == 0
+        assert not np.isnan(blob).any()
+        # every layer's Keras kernel, its fragment image (== pcc_conv_pack_weights) and its bias appear in the blob, in order
+        pos, cin = 0, (1 if name.startswith('Analysis') else F)
+        al = lambda v: (v + 63) // 64 * 64
+        for i, (kind, cout, k, s, bias, relu, res) in enumerate(ref):
+            w = kernels[i].ravel()
+            assert np.array_equal(blob[pos:pos + w.size], w)
+            pos += al(w.size)
+            dd = L.ConvDesc(1, 64, 64, 64, cin, cout, k, s, int(kind == 'convT'), 0, 0, 0, 0)
+            npk = lib.pcc_conv_packed_floats(C.byref(dd))
+            if npk:
+                pk = np.empty(npk, np.float32)
+                assert lib.pcc_conv_pack_weights(C.byref(dd), kernels[i].ctypes.data_as(C.c_void_p), pk.ctypes.data_as(C.c_void_p)) == 0
+                assert np.array_equal(blob[pos:pos + npk], pk)
+            pos += al(npk)
+            if bias:
+                assert np.array_equal(blob[pos:pos + cout], biases[i])
+                pos += al(cout)
+            cin = cout
+        assert pos == n
+    assert lib.pcc_network_num_layers(8, 32) < 0 and lib.pcc_weights_blob_floats(99, 32) == 0
 
 
 def test_ctx_create_fails_loudly_without_gpu():
