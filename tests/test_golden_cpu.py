@@ -161,3 +161,40 @@ def test_ply_roundtrip(tmp_path):
     assert_array_equal(pc_io.load_normals(p), n)
     pmin, pmax, shape = pc_io.get_shape_data(64, 'channels_first')
     assert list(shape) == [1, 64, 64, 64] and list(pc_io.get_shape_data(64, 'channels_last')[2]) == [64, 64, 64, 1]
+
+
+def test_tf_checkpoint_reader_against_hand_assembled_bundle(tmp_path):
+    """pcc_geo_cnn_v2_amd/tf_checkpoint.py against tests/golden/tf_bundle/: a TensorBundle assembled byte by byte from the
+    published format constants by tests/golden/make_tf_bundle.py (no code shared with the reader or with the test-side writer
+    tests/tf_bundle_writer.py): two data shards, a snappy-compressed index block (literal, copy-1, copy-2 elements),
+    prefix-compressed keys, masked CRC-32C everywhere."""
+    import shutil
+    from pcc_geo_cnn_v2_amd import tf_checkpoint as T
+    src = os.path.join(G, 'tf_bundle')
+    prefix = T.latest_checkpoint(src)
+    assert os.path.basename(prefix) == 'model.ckpt-4242'
+    header, entries = T.read_index(prefix, verify=True)
+    assert header['num_shards'] == 2 and {e['shard_id'] for e in entries.values()} == {0, 1}
+    got = T.load_checkpoint(prefix, verify=True)
+    exp = np.load(os.path.join(src, 'expected.npz'))
+    assert sorted(got) == sorted(k.replace('|', '/') for k in exp.files) and len(got) == 12
+    for k in exp.files:
+        a, b = got[k.replace('|', '/')], exp[k]
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), k
+    assert got['global_step'] == 4242 and got['unused/empty'].shape == (0, 3)
+    # checksums are really checked: flip one bit of the compressed index block / of a tensor
+    dst = str(tmp_path / 'b')
+    shutil.copytree(src, dst)
+    p = os.path.join(dst, 'model.ckpt-4242')
+    raw = bytearray(open(p + '.index', 'rb').read())
+    raw[300] ^= 0x10
+    open(p + '.index', 'wb').write(bytes(raw))
+    with pytest.raises((AssertionError, ValueError, IndexError)):
+        T.load_checkpoint(p, verify=True)
+    shutil.copy(os.path.join(src, 'model.ckpt-4242.index'), p + '.index')
+    raw = bytearray(open(p + '.data-00001-of-00002', 'rb').read())
+    raw[7] ^= 1
+    open(p + '.data-00001-of-00002', 'wb').write(bytes(raw))
+    with pytest.raises(AssertionError):
+        T.load_checkpoint(p, verify=True)
+    T.load_checkpoint(p, verify=False)
