@@ -1,42 +1,81 @@
 """Turns gpurun_out/<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/."""
-import collections, csv, glob, json, os, shutil, subprocess, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+import collections, csv, glob, json, os, re, shutil, subprocess, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, 'trace', 't_kernel_stats.csv'), os.path.join(dst, f'{tag}_bench_kernel_stats.csv'))
+shutil.copy(glob.glob(os.path.join(src, 'trace', '**', 't_kernel_stats.csv'), recursive=True)[0], os.path.join(dst, f'{tag}_bench_kernel_stats.csv'))
 summary = subprocess.check_output([sys.executable, os.path.join(root, 'tools', 'summarize_trace.py'),
-                                   os.path.join(src, 'trace', 't_kernel_trace.csv'), '6', '34'], text=True)
+                                   glob.glob(os.path.join(src, 'trace', '**', 't_kernel_trace.csv'), recursive=True)[0], '6', '34'], text=True)
 bench_prof = [l for l in open(os.path.join(src, 'bench_profiled.log')) if l.startswith('{"metric"')]
 bench = [l for l in open(os.path.join(src, 'bench.log')) if l.startswith('{"metric"')]
-pmc = {}
-for d in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_lds'):
-    for f in glob.glob(os.path.join(src, d, '*counter_collection.csv')):
-        agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if 'conv16_wino' in r['Kernel_Name'] or 'conv16_pers' in r['Kernel_Name']:
-                agg[r['Counter_Name']].append(float(r['Counter_Value']))
-        for k, v in agg.items():
-            pmc[k] = sum(v) / len(v)
+PEAK_TF, HBM_TBS = 157.3, 8.0
 B = 32
-alg = B * 64 ** 3 * 16 * 4 * 3            # in + residual + out, bytes per launch
-fetch = pmc.get('FETCH_SIZE', float('nan')) * 1024 * 2   # KB -> B, x2: gfx950 FETCH_SIZE counts 64 B per 128 B request
-write = pmc.get('WRITE_SIZE', float('nan')) * 1024
-traffic = fetch + write
-simd_cycles = pmc.get('GRBM_GUI_ACTIVE', float('nan')) / 8 * 1024   # per-XCD cycles x 1024 SIMDs
-out = {'kernel': 'conv16_wino_kernel<relu,clip> (Winograd F(2x2,3x3)+direct z), Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32',
-       'hbm_bytes_per_launch': traffic, 'fetch_bytes_corrected_x2': fetch, 'write_bytes': write,
-       'algorithmic_bytes_per_launch': alg, 'traffic_over_algorithmic': traffic / alg,
-       'l2_hit_rate': pmc.get('TCC_HIT_sum', 0) / max(pmc.get('TCC_HIT_sum', 0) + pmc.get('TCC_MISS_sum', 0), 1),
-       'mfma_busy_frac': pmc.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) / simd_cycles,
-       'lds_bank_conflict_frac_of_lds_cycles': pmc.get('SQ_LDS_BANK_CONFLICT', 0) / max(pmc.get('SQ_LDS_IDX_ACTIVE', 1), 1),
-       'raw_counters': pmc,
-       'method': 'rocprofv3 --pmc, one pass per counter group, on tools/bench_one.py 32 64 16 16 3 1 1 res; FETCH_SIZE doubled per '
-                 'MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B fabric request); WRITE_SIZE as reported (uncalibrated)'}
-json.dump(out, open(os.path.join(dst, 'dominant_kernel_traffic.json'), 'w'), indent=1)
+# key -> (kernel name fragment, description, algorithmic flops per launch, executed-MFMA flops per launch (None = counter), algorithmic bytes, bound)
+KERNELS = {
+    'wino16': ('conv16_wino_kernel', 'Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32 (Winograd F(2x2,3x3) x-y + direct z)',
+               2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'mfma'),
+    'tr2g': ('conv_tr2g_kernel', 'Conv3DTranspose 32->16 k3 s2 32^3 -> 64^3, batch 32 (parity-decomposed, persistent)',
+             2.0 * B * 32 ** 3 * 27 * 32 * 16, B * (32 ** 3 * 32 + 64 ** 3 * 16) * 4, 'mfma'),
+    'cout1': ('conv_cout1_mfma_kernel', 'Conv3DTranspose 16->1 k3 s1 @64^3, batch 32 (tap-plane MFMA + LDS gather)',
+              2.0 * B * 64 ** 3 * 27 * 16, B * 64 ** 3 * (16 + 1) * 4, 'hbm'),
+}
+rows, traffic_json = [], None
+for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
+    pmc, dur = {}, []
+    for d in ('fetch', 'write', 'sq', 'lds'):
+        for f in glob.glob(os.path.join(src, key, d, '**', '*counter_collection.csv'), recursive=True):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if frag in r['Kernel_Name']:
+                    agg[r['Counter_Name']].append(float(r['Counter_Value']))
+            for k, v in agg.items():
+                pmc[k] = sum(v) / len(v)
+        if d == 'sq':   # launch duration of the profiled (counter) pass, from its own kernel trace
+            for f in glob.glob(os.path.join(src, key, d, '**', '*kernel_trace.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if frag in r['Kernel_Name']:
+                        dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    tl = open(os.path.join(src, key, 'time.log')).read()
+    m = re.search(r'min ([\d.]+) us median ([\d.]+) us', tl)
+    t_min, t_med = (float(m.group(1)), float(m.group(2))) if m else (float('nan'),) * 2
+    fetch = pmc.get('FETCH_SIZE', float('nan')) * 1024 * 2      # KB -> B, x2: gfx950 FETCH_SIZE counts 64 B per 128 B request (MI355X_MICROARCH.md)
+    write = pmc.get('WRITE_SIZE', float('nan')) * 1024
+    exec_flops = pmc.get('SQ_INSTS_VALU_MFMA_MOPS_F32', float('nan')) * 512
+    simd_cycles = pmc.get('GRBM_GUI_ACTIVE', float('nan')) / 8 * 1024
+    out = {'key': key, 'kernel': frag, 'layer': desc, 'bound': bound,
+           'launch_us_unprofiled_min': t_min, 'launch_us_unprofiled_median': t_med,
+           'launch_us_in_counter_pass': sum(dur) / max(len(dur), 1),
+           'algorithmic_flops_per_launch': alg_flops, 'executed_mfma_flops_per_launch': exec_flops,
+           'executed_tflops': exec_flops / (t_med * 1e-6) / 1e12, 'executed_frac_of_fp32_mfma_peak': exec_flops / (t_med * 1e-6) / 1e12 / PEAK_TF,
+           'algorithmic_tflops': alg_flops / (t_med * 1e-6) / 1e12,
+           'mfma_busy_frac_of_simd_cycles': pmc.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) / simd_cycles,
+           'mfma_busy_frac_of_wave_cycles': pmc.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) / 4 / pmc.get('SQ_WAVE_CYCLES', float('nan')),
+           'shader_clock_ghz_in_counter_pass': pmc.get('GRBM_GUI_ACTIVE', float('nan')) / 8 / (sum(dur) / max(len(dur), 1)) / 1e3,
+           'algorithmic_bytes_per_launch': alg_bytes, 'hbm_bytes_per_launch': fetch + write, 'fetch_bytes_corrected_x2': fetch, 'write_bytes': write,
+           'traffic_over_algorithmic': (fetch + write) / alg_bytes,
+           'hbm_tbs_algorithmic': alg_bytes / (t_med * 1e-6) / 1e12, 'hbm_frac_of_8tbs': alg_bytes / (t_med * 1e-6) / 1e12 / HBM_TBS,
+           'l2_hit_rate': pmc.get('TCC_HIT_sum', 0) / max(pmc.get('TCC_HIT_sum', 0) + pmc.get('TCC_MISS_sum', 0), 1),
+           'wait_any_frac': pmc.get('SQ_WAIT_ANY', float('nan')) / pmc.get('SQ_WAVE_CYCLES', float('nan')),
+           'lds_bank_conflict_frac_of_lds_cycles': pmc.get('SQ_LDS_BANK_CONFLICT', 0) / max(pmc.get('SQ_LDS_IDX_ACTIVE', 1), 1),
+           'raw_counters': pmc}
+    rows.append(out)
+    if key == 'wino16':
+        traffic_json = dict(out, method='rocprofv3 --pmc, one pass per counter group, on tools/bench_one.py 32 64 16 16 3 1 1 res; FETCH_SIZE doubled per '
+                            'MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B fabric request); WRITE_SIZE as reported (uncalibrated)')
+json.dump(traffic_json, open(os.path.join(dst, 'dominant_kernel_traffic.json'), 'w'), indent=1)
+json.dump(rows, open(os.path.join(dst, f'{tag}_kernel_counters.json'), 'w'), indent=1)
 with open(os.path.join(dst, f'{tag}_bench_kernel_summary.md'), 'w') as f:
     f.write(f'# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline`\n\n')
     f.write('6 steps of 32 blocks (1 warm-up + 5 timed), c3p @64^3, per (kernel, grid size):\n\n' + summary + '\n')
     f.write('bench.py JSON under the profiler:\n\n```\n' + ''.join(bench_prof) + '```\n\nbench.py JSON without the profiler (same box):\n\n```\n' + ''.join(bench) + '```\n\n')
-    f.write('Dominant-kernel counters (separate `--pmc` passes):\n\n```\n' + json.dumps(out, indent=1) + '\n```\n')
-print(json.dumps({k: out[k] for k in ('hbm_bytes_per_launch', 'algorithmic_bytes_per_launch', 'traffic_over_algorithmic', 'mfma_busy_frac', 'l2_hit_rate')}, indent=1))
+    f.write('## Counters of the three kernels VERDICT r01 names (separate `--pmc` passes on `tools/bench_one.py`, batch 32)\n\n')
+    f.write('| kernel | launch us (median, un-profiled) | executed MFMA GFLOP | executed frac of 157.3 TF | MFMA busy / SIMD cycles | MFMA busy / wave cycles | clock GHz (counter pass) | '
+            'HBM bytes / algorithmic | algorithmic TB/s (frac of 8) | wait_any | LDS conflict frac |\n|---|---|---|---|---|---|---|---|---|---|---|\n')
+    for o in rows:
+        f.write(f"| `{o['kernel']}` {o['layer']} | {o['launch_us_unprofiled_median']:.1f} | {o['executed_mfma_flops_per_launch']/1e9:.2f} | {o['executed_frac_of_fp32_mfma_peak']:.3f} | "
+                f"{o['mfma_busy_frac_of_simd_cycles']:.3f} | {o['mfma_busy_frac_of_wave_cycles']:.3f} | {o['shader_clock_ghz_in_counter_pass']:.2f} | {o['traffic_over_algorithmic']:.3f} | "
+                f"{o['hbm_tbs_algorithmic']:.2f} ({o['hbm_frac_of_8tbs']:.2f}) | {o['wait_any_frac']:.3f} | {o['lds_bank_conflict_frac_of_lds_cycles']:.3f} |\n")
+    f.write(f'\nFull counter sets: `profiles/{tag}_kernel_counters.json`.  `executed MFMA GFLOP` = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512; HBM bytes = FETCH_SIZE x 2 (gfx950 '
+            'correction, MI355X_MICROARCH.md) + WRITE_SIZE.\n')
+print(json.dumps([{k: o[k] for k in ('key', 'launch_us_unprofiled_median', 'executed_frac_of_fp32_mfma_peak', 'mfma_busy_frac_of_simd_cycles', 'traffic_over_algorithmic', 'hbm_frac_of_8tbs')} for o in rows], indent=1))
