@@ -472,17 +472,29 @@ class CompressionModel:
                     pts = cnt_d.cpu().numpy()
             return strings, ce, pts
 
-        for x in dense_chunks:
-            B, dhw = x.shape[0], tuple(x.shape[1:4])
-            enc = self._encode_batch(ctx, x, False, thr=self._thr_tensor(ctx, [thr_idx] * B))
-            cnt_e = enc['counts']
+        def stage_a(item):
+            enc, dhw, B = item
             strings = enc['finish']()
             st = self._decode_phase_a(ctx, strings, dhw)
-            q_b.append((strings, cnt_e, st, dhw, B))
+            q_b.append((strings, enc['counts'], st, dhw, B))
             if len(q_b) > 1:
                 q_g.append(stage_b(q_b.pop(0)))
+
+        # The GPU work of chunk k+1 (compress graph) is enqueued BEFORE the host waits for the symbols of chunk k: the device
+        # queue then always holds at least one more compress graph than the host coder needs to stay ahead of, so a slow or
+        # noisy host does not drain it.  Pinned symbol buffers are per slot (three chunks can be between enqueue and coding).
+        q_a, k = [], 0
+        for x in dense_chunks:
+            B, dhw = x.shape[0], tuple(x.shape[1:4])
+            enc = self._encode_batch(ctx, x, False, thr=self._thr_tensor(ctx, [thr_idx] * B), slot=k % 3)
+            k += 1
+            q_a.append((enc, dhw, B))
+            if len(q_a) > 1:
+                stage_a(q_a.pop(0))
             if len(q_g) > 1:
                 yield stage_g(q_g.pop(0))
+        while q_a:
+            stage_a(q_a.pop(0))
         while q_b:
             q_g.append(stage_b(q_b.pop(0)))
         while q_g:
@@ -584,7 +596,7 @@ class CompressionModelV1(CompressionModel):
         self.init_weights()
 
     # ---- batched graph
-    def _encode_batch(self, ctx, x, debug, thr=None):
+    def _encode_batch(self, ctx, x, debug, thr=None, slot=0):
         B = x.shape[0]
         eb = self.entropy_bottleneck
         codec = self._codec(ctx)
@@ -599,7 +611,7 @@ class CompressionModelV1(CompressionModel):
             med = self._dev(ctx, 'medians', eb.medians)
             y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
             ysym, y_hat = ops.quantize(ctx, y, med, self.round_mode)
-        ysym_h = self._pinned.get('ysym', self._stream_shape(B, ysym.shape[1:4], self.num_filters), torch.int32)
+        ysym_h = self._pinned.get(('ysym', slot), self._stream_shape(B, ysym.shape[1:4], self.num_filters), torch.int32)
         ev = self._copy_out(ctx, [(ysym_h, ysym)], ready)
         if codec is None:
             x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
@@ -711,7 +723,7 @@ class CompressionModelV2(CompressionModel):
         self.init_weights()
 
     # ---- batched graph: x -A-> y -HA-> z -EB-> z_string ; z_hat -HS-> sigma ; (y, sigma) -GC-> y_string ; y_hat -S-> x_hat
-    def _encode_batch(self, ctx, x, debug, thr=None):
+    def _encode_batch(self, ctx, x, debug, thr=None, slot=0):
         B = x.shape[0]
         F = self.num_filters
         eb, gc = self.entropy_bottleneck, self.conditional_bottleneck
@@ -733,9 +745,9 @@ class CompressionModelV2(CompressionModel):
             sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
             idx = ops.scale_to_index(ctx, sigma, tab)
             ysym, y_hat = ops.quantize(ctx, y, None, self.round_mode)
-        zsym_h = self._pinned.get('zsym', self._stream_shape(B, zsym.shape[1:4], F), torch.int32)
-        ysym_h = self._pinned.get('ysym', self._stream_shape(B, ysym.shape[1:4], F), torch.int32)
-        idx_h = self._pinned.get('idx', self._stream_shape(B, idx.shape[1:4], F), torch.int32)
+        zsym_h = self._pinned.get(('zsym', slot), self._stream_shape(B, zsym.shape[1:4], F), torch.int32)
+        ysym_h = self._pinned.get(('ysym', slot), self._stream_shape(B, ysym.shape[1:4], F), torch.int32)
+        idx_h = self._pinned.get(('idx', slot), self._stream_shape(B, idx.shape[1:4], F), torch.int32)
         # symbols leave on a side stream (permutation into stream order + copy) so that they overlap the synthesis transform:
         # `ready` is recorded by the library between the last quantiser and the first synthesis layer
         ev = self._copy_out(ctx, [(zsym_h, zsym), (ysym_h, ysym), (idx_h, idx)], ready)
