@@ -74,6 +74,59 @@ def compute_optimal_thresholds(block, x_hat, thresholds, resolution, normals=Non
     return ret_opt_metrics, best_thresholds
 
 
+class HostSearchPool:
+    """Persistent pool of worker PROCESSES (pcc_geo_cnn_v2_amd.search_worker) for the host KD-tree threshold search: the blocks
+    of a chunk are independent, the reference searches them one after the other (model_types.py:192-212).  Subprocesses
+    with pipes instead of multiprocessing: no fork of a process that holds a HIP context, no re-import of the caller's
+    __main__.  Decisions are those of compute_optimal_thresholds (same code, same scipy)."""
+
+    def __init__(self, n_workers):
+        import os
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), OMP_NUM_THREADS='1')
+        self.procs = [subprocess.Popen([sys.executable, '-m', 'pcc_geo_cnn_v2_amd.search_worker'], stdin=subprocess.PIPE,
+                                       stdout=subprocess.PIPE, env=env) for _ in range(max(1, int(n_workers)))]
+
+    def map(self, jobs):
+        """jobs: list of (block, x_hat, thresholds, resolution, with_normals, opt_metrics, max_deltas).  Returns
+        [(names, best)] in order.  Each worker handles jobs i, i + W, i + 2W, ... through its own pipe."""
+        import pickle
+        import struct
+        from concurrent.futures import ThreadPoolExecutor
+        W = len(self.procs)
+        out = [None] * len(jobs)
+
+        def drive(w):
+            p = self.procs[w]
+            for i in range(w, len(jobs), W):
+                data = pickle.dumps(jobs[i], protocol=4)
+                p.stdin.write(struct.pack('<Q', len(data)) + data)
+                p.stdin.flush()
+                n = struct.unpack('<Q', p.stdout.read(8))[0]
+                status, a, b = pickle.loads(p.stdout.read(n))
+                if status != 'ok':
+                    raise AssertionError(f'threshold search worker: {a}')
+                out[i] = (a, b)
+
+        with ThreadPoolExecutor(max_workers=W) as ex:
+            list(ex.map(drive, range(min(W, len(jobs)))))
+        return out
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+        self.procs = []
+
+    def __del__(self):
+        self.close()
+
+
 def select_thresholds_from_stats(block, s_ab, s_ba, n_b, tcount, n_thresholds, resolution, opt_metrics, max_deltas):
     """The decision logic of compute_optimal_thresholds (model_opt.py:33-73) applied to exact per-threshold D1 sums
     (integers) of one block, as produced by ops.d1_threshold_stats.  Only d1_* metrics (no normals)."""

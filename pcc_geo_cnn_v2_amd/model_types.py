@@ -98,7 +98,7 @@ class _Pinned:
 
 class CompressionModel:
     def __init__(self, n_thresholds=2 ** 8, data_format='channels_first', batch_size=32,
-                 round_mode=L.PCC_ROUND_FLOOR_HALF, coder_threads=0, seed=42, precision='fp32'):
+                 round_mode=L.PCC_ROUND_FLOOR_HALF, coder_threads=0, seed=42, precision='fp32', search_threads=0):
         assert precision in ('fp32', 'fp16'), "precision: 'fp32' (the reference's arithmetic) or 'fp16' (fp16 matrix instructions, fp32 accumulate)"
         self.precision = precision
         self.thresholds = np.linspace(0, 1.0, n_thresholds)
@@ -106,6 +106,7 @@ class CompressionModel:
         self.batch_size = int(batch_size)
         self.round_mode = round_mode
         self.coder_threads = coder_threads
+        self.search_threads = search_threads      # worker processes of the host KD-tree threshold search (0 = min(cores, 64))
         self.seed = seed
         self.x_shape = None
         self._pinned = _Pinned()
@@ -196,6 +197,16 @@ class CompressionModel:
             f'block-local coordinates outside the {dhw} grid'
         bof = np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(blocks)])
         return ops.voxelize(ctx, torch.from_numpy(pts).to(ctx.device), torch.from_numpy(bof).to(ctx.device), B, D, H, W)
+
+    def _search_pool(self, n_jobs):
+        from .model_opt import HostSearchPool
+        want = max(1, min(n_jobs, self.search_threads or min(os.cpu_count() or 1, 64)))
+        pool = getattr(self, '_host_search_pool', None)
+        if pool is None or len(pool.procs) < want:
+            if pool is not None:
+                pool.close()
+            self._host_search_pool = pool = HostSearchPool(want)
+        return pool
 
     def _thr_tensor(self, ctx, thr_idx):
         """float32 thresholds of the blocks of a chunk as a device tensor."""
@@ -338,14 +349,19 @@ class CompressionModel:
                     threshold_list.append(list(best_all[j]))
                     x_hat_list.append([per_metric[m][j] for m in range(n_m)])
             else:
+                # D2 / normals: the reference's numbers depend on WHICH of several equidistant nearest neighbours scipy's
+                # KD-tree returns (measured: another tie rule moves d2_mse by up to 60 % and the chosen threshold in 2 of 6
+                # blocks), so identical decisions need the same KD-tree: host path, one block per host thread (the KD-tree
+                # per worker process of a persistent pool; the reference runs the blocks one after the other, model_types.py:192-212)
                 strings = enc['finish']()
                 xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)
-                for j, block in enumerate(chunk):
-                    normals = get_normals_if(block, with_normals)
-                    opt_metrics_ret, best = compute_optimal_thresholds(block, xh[j], self.thresholds, resolution,
-                                                                       normals=normals, opt_metrics=opt_metrics,
-                                                                       max_deltas=max_deltas, fixed_threshold=False)
-                    best = list(best) + [best[-1]] * (len(max_deltas) * len(opt_metrics) - len(best))     # see above
+
+                n_m = len(max_deltas) * len(opt_metrics)
+                jobs = [(np.asarray(chunk[j], np.float64), xh[j], self.thresholds, resolution, with_normals, list(opt_metrics),
+                         list(max_deltas)) for j in range(len(chunk))]
+                for j, (names, best) in enumerate(self._search_pool(len(chunk)).map(jobs)):
+                    opt_metrics_ret = names
+                    best = list(best) + [best[-1]] * (n_m - len(best))     # see above
                     threshold_list.append(best)
                     x_hat_list.append([np.argwhere(xh[j] > self._thr32(t)).astype(np.float32) for t in best])
             strings_list.extend(strings)

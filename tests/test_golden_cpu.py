@@ -198,3 +198,29 @@ def test_tf_checkpoint_reader_against_hand_assembled_bundle(tmp_path):
     with pytest.raises(AssertionError):
         T.load_checkpoint(p, verify=True)
     T.load_checkpoint(p, verify=False)
+
+
+def test_host_search_pool_matches_reference_answers():
+    """model_opt.HostSearchPool (worker processes for the KD-tree threshold search used when normals / d2_* metrics are requested)
+    gives the reference's own answers on the fixtures and, with normals, the answers of the in-process call."""
+    f = np.load(os.path.join(G, 'model_opt.npz'), allow_pickle=True)
+    thr = np.linspace(0, 1.0, 256)
+    rng = np.random.default_rng(0)
+    jobs = [(f[f'm{i}_block'], f[f'm{i}_x_hat'], thr, 64, False, ['d1_mse', 'd1_sum_mean'], [np.inf]) for i in range(4)]
+    blk = np.hstack([f['m0_block'], rng.normal(size=f['m0_block'].shape)])
+    jobs.append((blk, f['m0_x_hat'], thr, 64, True, ['d1_mse', 'd2_mse'], [np.inf, 2.0]))
+    pool = model_opt.HostSearchPool(3)
+    try:
+        out = pool.map(jobs)
+        bad = pool.map([(f['m0_block'], f['m0_x_hat'], thr, 64, False, ['d2_mse'], [np.inf])])      # d2 without normals
+    except AssertionError as e:
+        assert 'not available without normals' in str(e)
+        bad = None
+    finally:
+        pool.close()
+    assert bad is None
+    for i in range(4):
+        assert out[i][1] == [int(v) for v in f[f'm{i}_best_fixed0']] and list(out[i][0]) == list(f[f'm{i}_names_fixed0'])
+    names, best = model_opt.compute_optimal_thresholds(blk, f['m0_x_hat'], thr, 64, normals=blk[:, 3:6], opt_metrics=['d1_mse', 'd2_mse'],
+                                                       max_deltas=[np.inf, 2.0])
+    assert out[4] == (names, [int(b) for b in best]) and len(best) == 4

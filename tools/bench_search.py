@@ -16,3 +16,12 @@ t0 = time.perf_counter(); names, best = model_opt.compute_optimal_thresholds_gpu
 xh = np.clip(x_hat.cpu().numpy(), 0, 1)
 t0 = time.perf_counter(); hb = [model_opt.compute_optimal_thresholds(blocks[i], xh[i], thr, 64, opt_metrics=['d1_mse'], max_deltas=[np.inf])[1] for i in range(4)]; t_host = (time.perf_counter() - t0) / 4
 print(f'GPU adaptive search: {1e3*t_gpu:.1f} ms for 32 blocks ({1e3*t_gpu/32:.2f} ms/block); host KD-tree path: {1e3*t_host:.0f} ms/block -> {t_host/(t_gpu/32):.0f}x; decisions equal: {hb == best[:4]}; best idx sample {best[:6]}')
+
+# D2 (normals): host KD-tree path, one block per worker process (model_opt.HostSearchPool) vs one after the other
+nb = [np.hstack([b, np.random.default_rng(i).normal(size=b.shape)]) for i, b in enumerate(blocks)]
+jobs = [(nb[i], xh[i], thr, 64, True, ['d1_mse', 'd2_mse'], [np.inf]) for i in range(32)]
+t0 = time.perf_counter(); serial = [model_opt.compute_optimal_thresholds(nb[i], xh[i], thr, 64, normals=nb[i][:, 3:6], opt_metrics=['d1_mse', 'd2_mse'], max_deltas=[np.inf])[1] for i in range(2)]; t_ser = (time.perf_counter() - t0) / 2
+pool = model_opt.HostSearchPool(32)
+t0 = time.perf_counter(); par = pool.map(jobs); t_par = (time.perf_counter() - t0) / 32
+pool.close()
+print(f'D2 host search: serial {1e3*t_ser:.0f} ms/block; 32 worker processes {1e3*t_par:.0f} ms/block ({t_ser/t_par:.1f}x); decisions equal: {[list(map(int, s)) for s in serial] == [p[1] for p in par[:2]]}; cores {os.cpu_count()}')
