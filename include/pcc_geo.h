@@ -60,6 +60,13 @@ int pcc_ctx_num_cu(pcc_ctx* ctx);
 #define PCC_CONV_F16 16    /* fp16 matrix instructions (operands rounded RTN, fp32 accumulate and storage) on the
                               direct MFMA kernels; BASELINE.json configs[4].  Not the default: the reference is fp32 */
 
+/* fp16 STORAGE inside the fp16 mode (mid-network tensors of the c3 / c3p blocks; used by pcc_network_forward with
+ * PCC_CONV_F16, accepted here for callers that chain layers themselves).  Buffers are passed through the same pointers.   */
+#define PCC_CONV_IN16 32   /* `in` (and `residual`, if any: see RES16) are fp16 NDHWC: k3 stride-1 layers with Cin = Cout in
+                              {16, 32} and H, W multiples of 16 (conv_f16.hip, v_mfma_f32_16x16x32_f16)                   */
+#define PCC_CONV_OUT16 64  /* `out` is fp16 NDHWC: the IN16 layers and the k3 stride-2 transposed layers                  */
+#define PCC_CONV_RES16 128 /* `residual` is fp16 (always together with IN16)                                              */
+
 #define PCC_IMPL_AUTO 0    /* MFMA implicit-GEMM when the shape is covered, else generic          */
 #define PCC_IMPL_GENERIC 1 /* direct convolution, any shape (reference-order fp32 FMA chain)      */
 #define PCC_IMPL_MFMA 2    /* force the direct MFMA implicit-GEMM path; PCC_ERR_ARG if not covered */

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PCC_GEO_LIB', os.path.join(_HERE, 'libpcc_geo_hip.so'))   # override: A/B builds
 
 PCC_CONV_BIAS, PCC_CONV_RELU, PCC_CONV_ADD, PCC_CONV_CLIP01, PCC_CONV_F16 = 1, 2, 4, 8, 16
+PCC_CONV_IN16, PCC_CONV_OUT16, PCC_CONV_RES16 = 32, 64, 128          # fp16 storage inside the fp16 mode
 PCC_IMPL_AUTO, PCC_IMPL_GENERIC, PCC_IMPL_MFMA, PCC_IMPL_WINOGRAD = 0, 1, 2, 3
 PCC_ROUND_FLOOR_HALF, PCC_ROUND_HALF_EVEN = 0, 1
 

@@ -53,5 +53,11 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 bool pcc_wino_eligible(const pcc_conv_desc* d);
 int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed,
                   const float* bias, const float* residual, float* out, hipStream_t st);
+// fp16-storage k3 stride-1 kernel for Cin = Cout in {16, 32} (conv_f16.hip), PCC_CONV_IN16 layers
+bool pcc_f16_eligible(const pcc_conv_desc* d);
+size_t pcc_f16_packed_bytes(int C);
+void pcc_f16_pack(int C, const float* wlog, unsigned short* out);
+int pcc_conv_f16(pcc_ctx* ctx, const pcc_conv_desc* d, const void* in, const void* w_packed, const float* bias,
+                 const void* residual, void* out, bool out32, hipStream_t st);
 constexpr int PCC_WINO_U_FLOATS = 48 * 64 * 4;   // per (cin group, cout group): [z tap][point][lane][cin quad member]
 inline bool pcc_wino_channels(int cin, int cout) { return cin == cout && (cin == 16 || cin == 32 || cin == 64); }

@@ -34,6 +34,7 @@ namespace pccmfma {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -921,7 +922,10 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
                         }
                 if (g == C::NG - 1) {      // (wave-uniform) this class is complete: bias / ReLU / residual / clip, stores
                 const size_t cvox = ((size_t)pz * a.OH + py) * a.OW + px;
-                const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + ((size_t)n * ovox_n + cvox) * a.ocs, (unsigned)((ovox_n - cvox) * a.ocs * 4));
+                const bool out16 = (a.flags & PCC_CONV_OUT16) != 0;       // (wave-uniform) fp16 hand-over to conv_f16.hip
+                const __amdgpu_buffer_rsrc_t rout = out16
+                    ? make_rsrc((const unsigned short*)a.out + ((size_t)n * ovox_n + cvox) * a.ocs, (unsigned)((ovox_n - cvox) * a.ocs * 2))
+                    : make_rsrc(a.out + ((size_t)n * ovox_n + cvox) * a.ocs, (unsigned)((ovox_n - cvox) * a.ocs * 4));
                 const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + ((size_t)n * ovox_n + cvox) * COUT : a.in, has_res ? (unsigned)((ovox_n - cvox) * COUT * 4) : 0u);
 #pragma unroll
                 for (int ct = 0; ct < CTW; ++ct)
@@ -936,6 +940,13 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
                             for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
                         }
                         // immediate soffset: the compiler guards the store-data hazard of this form (see conv_wino.hip)
+                        if (out16) {
+                            h16x4 oh;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) oh[c] = (_Float16)o[c];
+                            const unsigned off = ooff[i] == kOOB ? kOOB : (ooff[i] + (unsigned)((ct0 + ct) * 64)) >> 1;
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oh), rout, (int)(off | dbg_nostore), 0, 0);
+                        } else
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)((ooff[i] + (unsigned)((ct0 + ct) * 64)) | dbg_nostore), 0, 0);
                     }
                 }
@@ -1412,6 +1423,7 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
 #define PCC_TR2C(TX, TZ, TY, TXT, R, CTW)                                                               \
     {                                                                                                   \
         using C = Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>;                                       \
+        if (a.flags & PCC_CONV_OUT16) { pcc_set_error("pcc_conv3d: PCC_CONV_OUT16 needs the k3 group-pipelined transposed kernel (input W multiple of 8)"); return PCC_ERR_ARG; } \
         a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
         if (a.flags & PCC_CONV_F16)                                                                     \
             return launch(conv_tr2_kernel<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW, true>, C::NT, C::LDS_BYTES, \
@@ -1514,7 +1526,8 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
         case K_FWD:
             // 16->16 / 32->32 k3 stride-1 layers also carry the Winograd-transformed weights (conv_wino.hip)
             if (pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && d->stride == 1)
-                return k3 * d->Cin * d->Cout + (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_U_FLOATS;
+                return k3 * d->Cin * d->Cout + (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_U_FLOATS +
+                       (d->Cin <= 32 ? pcc_f16_packed_bytes(d->Cin) / 4 : 0);     // + the fp16 fragments of conv_f16.hip
             return k3 * d->Cin * d->Cout;
         case K_TR2: return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1);     // k3: second copy in the order of conv_tr2g_kernel
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
@@ -1562,6 +1575,15 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                                 s += G[py][ky] * G[px][kx] * (double)Wf(kz, ky, kx, 16 * cig + 4 * (lane >> 4) + kk, 16 * cog + (lane & 15));
                             u[(((size_t)(cig * NCT + cog) * 48 + (kz * 4 + py) * 4 + px) * 64 + lane) * 4 + kk] = (float)s;
                         }
+            if (Cin <= 32) {      // fp16 fragment image of conv_f16.hip behind the Winograd block
+                float* wlog = (float*)malloc((size_t)27 * Cin * Cout * sizeof(float));
+                PCC_REQUIRE(wlog != nullptr, "pcc_conv_pack_weights: out of memory");
+                for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
+                    for (int ci = 0; ci < Cin; ++ci) for (int co = 0; co < Cout; ++co)
+                        wlog[((((size_t)kz * 3 + ky) * 3 + kx) * Cin + ci) * Cout + co] = Wf(kz, ky, kx, ci, co);
+                pcc_f16_pack(Cin, wlog, (unsigned short*)(u + (size_t)NG * NCT * PCC_WINO_U_FLOATS));
+                free(wlog);
+            }
         }
     } else if (p.kind == K_TR2) {
         // consumption order of conv_tr2_kernel: [parity class (pz,py,px)][taps of the class (kz,ky,kx)][g][ct][lane][j]
@@ -1632,7 +1654,15 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 
 #define PCC_CASE_FWD(CI, CO, K, S) if (ci == CI && co == CO && k == K && fs == S) return launch_fwd<CI, CO, K, S>(p.tx, a, st, ctx->num_cu);
 #define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st, ctx->num_cu);
+    if (d->flags & (PCC_CONV_IN16 | PCC_CONV_RES16)) {
+        // fp16-storage layer (conv_f16.hip): fp16 input (and residual), fp16 or fp32 output
+        PCC_REQUIRE(p.kind == K_FWD && (d->flags & PCC_CONV_IN16) && pcc_f16_eligible(d),
+                    "pcc_conv3d: PCC_CONV_IN16 covers k3 stride-1 layers with Cin = Cout in {16, 32} and H, W multiples of 16");
+        const float* f16w = w_packed + (size_t)27 * ci * co + (size_t)(ci / 16) * (co / 16) * PCC_WINO_U_FLOATS;
+        return pcc_conv_f16(ctx, d, in, f16w, bias, residual, out, !(d->flags & PCC_CONV_OUT16), st);
+    }
     if (p.kind == K_FWD) {
+        PCC_REQUIRE(!(d->flags & PCC_CONV_OUT16), "pcc_conv3d: PCC_CONV_OUT16 is implemented by the k3 stride-2 transposed kernel and the fp16 layers");
         const int fs = p.flip ? 1 : s;
         if (pcc_wino_channels(ci, co) && k == 3 && fs == 1) {
             static const bool no_wino = getenv("PCC_NO_WINOGRAD") != nullptr;

@@ -81,12 +81,22 @@ PCC_API int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
                 "pcc_conv3d: out_cstride too small");
     {   // bits 27..30 are profiling aids of conv_tr2g_kernel (skip stores / staging / weights): accepted only on request
         static const bool prof = getenv("PCC_PROFILE_FLAGS") != nullptr;
-        const int32_t known = PCC_CONV_BIAS | PCC_CONV_RELU | PCC_CONV_ADD | PCC_CONV_CLIP01 | PCC_CONV_F16;
+        const int32_t known = PCC_CONV_BIAS | PCC_CONV_RELU | PCC_CONV_ADD | PCC_CONV_CLIP01 | PCC_CONV_F16 | PCC_CONV_IN16 | PCC_CONV_OUT16 | PCC_CONV_RES16;
         PCC_REQUIRE((d->flags & ~(known | (prof ? 0x78000000 : 0))) == 0, "pcc_conv3d: unknown bits in flags");
     }
+    PCC_REQUIRE(!(d->flags & (PCC_CONV_IN16 | PCC_CONV_OUT16 | PCC_CONV_RES16)) || (d->flags & PCC_CONV_F16),
+                "pcc_conv3d: fp16 storage (IN16 / OUT16 / RES16) exists only inside the fp16 mode (PCC_CONV_F16)");
+    PCC_REQUIRE(!(d->flags & PCC_CONV_RES16) || ((d->flags & PCC_CONV_IN16) && (d->flags & PCC_CONV_ADD)),
+                "pcc_conv3d: PCC_CONV_RES16 goes with PCC_CONV_IN16 | PCC_CONV_ADD");
+    PCC_REQUIRE(!(d->flags & PCC_CONV_IN16) || !(d->flags & PCC_CONV_ADD) || (d->flags & PCC_CONV_RES16),
+                "pcc_conv3d: an fp16-input layer takes its residual in fp16 (PCC_CONV_RES16)");
     PCC_CHECK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const bool fast_ok = w_packed != nullptr && pcc_conv_mfma_supported(d) == 1;
+    if (d->flags & (PCC_CONV_IN16 | PCC_CONV_OUT16)) {
+        PCC_REQUIRE(fast_ok && d->impl == PCC_IMPL_AUTO, "pcc_conv3d: fp16 storage needs the packed weights and PCC_IMPL_AUTO");
+        return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
+    }
     if (d->impl == PCC_IMPL_MFMA || d->impl == PCC_IMPL_WINOGRAD) {
         PCC_REQUIRE(fast_ok, "pcc_conv3d: PCC_IMPL_MFMA/WINOGRAD requested but shape not covered or w_packed NULL");
         return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);

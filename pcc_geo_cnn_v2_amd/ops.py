@@ -298,6 +298,27 @@ def profile_read(ctx, cap=8192):
     return [ms[i] for i in range(n.value)]
 
 
+def conv3d_fp16_storage(ctx, x, layer, residual=None, in16=None, out16=True, flags=0):
+    """One layer of the fp16 mode with fp16 tensors in HBM (PCC_CONV_IN16 / OUT16 / RES16, include/pcc_geo.h): x fp16 (k3
+    stride-1 layers, Cin = Cout in {16, 32}) or fp32 (k3 stride-2 transposed layers, out16 only).  pcc_network_forward chains
+    these itself in the fp16 mode; this wrapper exists for tests and for callers that chain layers by hand."""
+    in16 = (x.dtype == torch.float16) if in16 is None else in16
+    assert x.is_contiguous() and x.device == ctx.device and x.dim() == 5 and x.dtype == (torch.float16 if in16 else torch.float32)
+    N, D, H, W, Cin = x.shape
+    assert Cin == layer.cin
+    oshape = conv_out_shape(layer, x.shape)
+    out = torch.empty(oshape, dtype=torch.float16 if out16 else torch.float32, device=ctx.device)
+    f = flags | L.PCC_CONV_F16 | (L.PCC_CONV_IN16 if in16 else 0) | (L.PCC_CONV_OUT16 if out16 else 0)
+    if residual is not None:
+        assert in16 and residual.dtype == torch.float16 and residual.is_contiguous() and tuple(residual.shape) == tuple(oshape)
+        f |= L.PCC_CONV_ADD | L.PCC_CONV_RES16
+    d = layer.desc(N, D, H, W, f)
+    im = layer.device_images(ctx, d)
+    L.check(L.lib().pcc_conv3d(ctx.handle, C.byref(d), _ptr(x), _ptr(im['w']), _ptr(im['pk']), _ptr(im['b']), _ptr(residual),
+                               _ptr(out), ctx.stream), 'pcc_conv3d')
+    return out
+
+
 def mfma_supported(layer, x_shape):
     N, D, H, W, _ = x_shape
     d = layer.desc(N, D, H, W)
