@@ -159,10 +159,17 @@ def main():
     ap.add_argument('--chunk', type=int, default=CHUNK)
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
                     help="fp32 = the reference's arithmetic (the headline number); fp16 = fp16 MFMA / fp32 accumulate (BASELINE.json configs[4] flavour, informational)")
+    ap.add_argument('--workload', default='configs1', choices=['configs1', 'configs4'],
+                    help='configs1 = BASELINE.json configs[1] (c3p, batch 32, 64^3: the headline); configs4 = configs[4] (deepest config, '
+                         '128^3 blocks, batch 8, fp16 MFMA): a SEPARATE, labelled line, never the headline')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / collective skeleton only (gloo on CPU, no GPU work, value is meaningless): used by the CPU tests')
     args = ap.parse_args()
 
+    global RES, BATCH, FLOPS_PER_BLOCK
+    if args.workload == 'configs4':
+        RES, BATCH, FLOPS_PER_BLOCK = 128, 8, 248.689e9          # c3p @128^3
+        args.precision, args.chunk = 'fp16', min(args.chunk, 8)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # bare `python bench.py --gpus N`: re-exec under torch.distributed.run (one rank per GPU); never a mislabeled 1-GPU run
         return self_launch(args.gpus)
@@ -258,31 +265,40 @@ def main():
             dom_kernel = 'conv16_pers_kernel<2,4,2,20,2> (Conv3DTranspose 16->16 k3 s1 @64^3, 4 launches per step)'
             dom_note = 'direct implicit-GEMM kernel (PCC_NO_WINOGRAD=1): executed == algorithmic flops'
         achieved_exec = exec_flops / (avg_ms * 1e-3) / 1e12
+        alg_bytes16 = 3.0 * args.chunk * RES ** 3 * 16 * 2            # fp16 mode: in + residual + out of the timed layer, fp16
         traffic, traffic_src = None, None
         prof = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
         if winograd and os.path.exists(prof):
             traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
             traffic_src = 'profiles/dominant_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; not re-measured in this run)'
         out = {
-            'metric': 'voxel_blocks_64cubed_per_sec_encode_decode', 'value': value, 'unit': 'blocks/s',
+            'metric': 'voxel_blocks_64cubed_per_sec_encode_decode' if args.workload == 'configs1' else
+                      'voxel_blocks_128cubed_per_sec_encode_decode_FP16_MODE_not_the_headline', 'value': value, 'unit': 'blocks/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'f16 operands / f32 accumulate (NOT the headline precision)', 'data': 'synthetic',
-            'config': {'workload': 'c3p, lambda-independent graph, batch=32 synthetic 64^3 occupancy grids per GPU, '
-                                   'fixed threshold idx 128, encode+decode (BASELINE.json configs[1])',
+            'config': {'workload': ('c3p, lambda-independent graph, batch=32 synthetic 64^3 occupancy grids per GPU, '
+                                    'fixed threshold idx 128, encode+decode (BASELINE.json configs[1])') if args.workload == 'configs1' else
+                                   ('deepest config (paper c6 = the c3p graph), batch=8 synthetic 128^3 occupancy grids per GPU, fp16 MFMA with fp16 '
+                                    'mid-network storage, fixed threshold idx 128, encode+decode (BASELINE.json configs[4])'),
                        'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'coder_threads_per_rank': coder_threads, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
                        'bytes_per_block': n_bytes / n_blocks, 'decoded_points_per_block': n_pts / n_blocks,
                        'conv_tflops_whole_step': value * FLOPS_PER_BLOCK / 1e12,
                        'conv_frac_of_fp32_mfma_peak_whole_step': value * FLOPS_PER_BLOCK / 1e12 / (PEAK_FP32_MFMA * world)},
-            'roofline': {'bound': 'mfma', 'kernel': dom_kernel,
+            'roofline': ({'bound': 'hbm', 'kernel': 'conv_f16_kernel<16> (fp16 storage, v_mfma_f32_16x16x32_f16): Conv3DTranspose 16->16 k3 s1 + fp16 residual, synthesis layer 8',
+                          'achieved': alg_bytes16 / (avg_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg_bytes16 / (avg_ms * 1e-3) / 1e9 / 8000.0,
+                          'traffic': None, 'algorithmic_bytes_per_launch': alg_bytes16, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms),
+                          'note': 'fp16 mode: the layer is HBM-bound (fp16 MFMA is 16x the fp32 rate); achieved = fp16 bytes of input + residual + '
+                                  'output / HIP-event launch time; HBM3E peak 8 TB/s, ~6.3 TB/s achievable (MI355X_MICROARCH.md)'}
+                         if args.precision == 'fp16' else {'bound': 'mfma', 'kernel': dom_kernel,
                          'achieved': achieved_exec, 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s', 'frac': achieved_exec / PEAK_FP32_MFMA,
                          'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': 3.0 * args.chunk * RES ** 3 * 16 * 4,
                          'executed_flops_per_launch': exec_flops, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms),
                          'algorithmic_flops_per_launch': flops_launch, 'algorithmic_tflops': achieved,
                          'algorithmic_speedup_vs_direct_roof': achieved / PEAK_FP32_MFMA,
-                         'note': dom_note},
+                         'note': dom_note}),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'configs1':
             out['cpu_baseline'] = cpu_baseline(model, w, x[:4].cpu().numpy())
         else:
             out['cpu_baseline'] = None

@@ -63,7 +63,8 @@ int pcc_ctx_num_cu(pcc_ctx* ctx);
 /* fp16 STORAGE inside the fp16 mode (mid-network tensors of the c3 / c3p blocks; used by pcc_network_forward with
  * PCC_CONV_F16, accepted here for callers that chain layers themselves).  Buffers are passed through the same pointers.   */
 #define PCC_CONV_IN16 32   /* `in` (and `residual`, if any: see RES16) are fp16 NDHWC: k3 stride-1 layers with Cin = Cout in
-                              {16, 32} and H, W multiples of 16 (conv_f16.hip, v_mfma_f32_16x16x32_f16)                   */
+                              {16, 32} and H, W multiples of 16 (conv_f16.hip, v_mfma_f32_16x16x32_f16), and the 16 -> 1
+                              k3 stride-1 transposed layer                                                                */
 #define PCC_CONV_OUT16 64  /* `out` is fp16 NDHWC: the IN16 layers and the k3 stride-2 transposed layers                  */
 #define PCC_CONV_RES16 128 /* `residual` is fp16 (always together with IN16)                                              */
 

@@ -1179,6 +1179,9 @@ struct Cout1M {
     static constexpr int PER_WAVE = (NTILE + 3) / 4;    // N-tiles per wave (6,5,5,5)
 };
 
+// IN16 (fp16 mode, PCC_CONV_IN16): the input is fp16 NDHWC; a lane's 4 channels are one 8-byte load and feed ONE
+// v_mfma_f32_16x16x16_f16 per tap tile instead of four fp32 MFMAs.
+template <bool IN16>
 __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
     using C = Cout1M;
     extern __shared__ __attribute__((aligned(16))) float P[];   // [27][NU]
@@ -1204,12 +1207,22 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
         const int ly = u / C::LYX, lx = u - ly * C::LYX;
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
         const bool ok = nt < C::NTILE && u < C::LYX * C::LYX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        voff[k] = ok ? (unsigned)((gy * a.W + gx) * 16 + cq * 4) * 4u : kOOB;
+        voff[k] = ok ? (unsigned)((gy * a.W + gx) * 16 + cq * 4) * (IN16 ? 2u : 4u) : kOOB;
         uidx[k] = u;
     }
-    const unsigned plane_bytes = (unsigned)a.H * a.W * 64u;
-    const float* inb = a.in + (size_t)n * a.D * a.H * a.W * 16;
+    const unsigned plane_bytes = (unsigned)a.H * a.W * (IN16 ? 32u : 64u);
+    const unsigned char* inb = (const unsigned char*)a.in + (size_t)n * a.D * plane_bytes;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)a.D * plane_bytes);
+    // fp16 input arrives as 4 halfs in the low half of the float4 slot (bit pattern), converted weights beside it
+    const h16x4 wA0h = __builtin_convertvector(wA0, h16x4), wA1h = __builtin_convertvector(wA1, h16x4);
+    auto load_in = [&](unsigned voff_, unsigned soff) -> f32x4 {
+        if constexpr (IN16) {
+            const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, (int)voff_, (int)soff, 0));
+            return __builtin_bit_cast(f32x4, (u32x4){r[0], r[1], 0u, 0u});
+        } else {
+            return buf_load4(rin, voff_, soff);
+        }
+    };
 
     // gather side: thread -> output column (y, x)
     const int oy = tid >> 4, ox = tid & 15;
@@ -1230,7 +1243,7 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
 
     f32x4 nxt[C::PER_WAVE];
 #pragma unroll
-    for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = buf_load4(rin, voff[k], 0);
+    for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = load_in(voff[k], 0);
     float accA = 0.f, accB = 0.f, accC = 0.f;   // outputs z = p+1, p, p-1
 
 #pragma unroll 1
@@ -1240,11 +1253,20 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
         for (int k = 0; k < C::PER_WAVE; ++k) cur[k] = nxt[k];
         if (p + 1 < a.D) {
 #pragma unroll
-            for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = buf_load4(rin, voff[k], (unsigned)(p + 1) * plane_bytes);
+            for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = load_in(voff[k], (unsigned)(p + 1) * plane_bytes);
         }
         // ---- (1) P = W x in for the haloed plane p
         f32x4 d0[C::PER_WAVE], d1[C::PER_WAVE];
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};      // first k-slot starts from the inline constant 0: no zero-init pass (VALU costs MFMA time)
+        if constexpr (IN16) {
+#pragma unroll
+            for (int k = 0; k < C::PER_WAVE; ++k) {
+                const u32x4 cb = __builtin_bit_cast(u32x4, cur[k]);
+                const h16x4 bh = __builtin_bit_cast(h16x4, (u32x2){cb[0], cb[1]});
+                d0[k] = __builtin_amdgcn_mfma_f32_16x16x16f16(wA0h, bh, zero4, 0, 0, 0);
+                d1[k] = __builtin_amdgcn_mfma_f32_16x16x16f16(wA1h, bh, zero4, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1252,6 +1274,7 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
                 d0[k] = mfma16(wA0[j], cur[k][j], j == 0 ? zero4 : d0[k]);
                 d1[k] = mfma16(wA1[j], cur[k][j], j == 0 ? zero4 : d1[k]);
             }
+        }
 #pragma unroll
         for (int k = 0; k < C::PER_WAVE; ++k) {
             if (wave + 4 * k < C::NTILE) {
@@ -1654,10 +1677,10 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 
 #define PCC_CASE_FWD(CI, CO, K, S) if (ci == CI && co == CO && k == K && fs == S) return launch_fwd<CI, CO, K, S>(p.tx, a, st, ctx->num_cu);
 #define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st, ctx->num_cu);
-    if (d->flags & (PCC_CONV_IN16 | PCC_CONV_RES16)) {
+    if ((d->flags & (PCC_CONV_IN16 | PCC_CONV_RES16)) && p.kind != K_COUT1M) {
         // fp16-storage layer (conv_f16.hip): fp16 input (and residual), fp16 or fp32 output
         PCC_REQUIRE(p.kind == K_FWD && (d->flags & PCC_CONV_IN16) && pcc_f16_eligible(d),
-                    "pcc_conv3d: PCC_CONV_IN16 covers k3 stride-1 layers with Cin = Cout in {16, 32} and H, W multiples of 16");
+                    "pcc_conv3d: PCC_CONV_IN16 covers k3 stride-1 layers with Cin = Cout in {16, 32} (H, W multiples of 16) and the 16 -> 1 transposed layer");
         const float* f16w = w_packed + (size_t)27 * ci * co + (size_t)(ci / 16) * (co / 16) * PCC_WINO_U_FLOATS;
         return pcc_conv_f16(ctx, d, in, f16w, bias, residual, out, !(d->flags & PCC_CONV_OUT16), st);
     }
@@ -1691,7 +1714,8 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 #undef PCC_CIN1
     } else if (p.kind == K_COUT1M) {
         a.ntz = 1; a.nty = cdiv(a.H, Cout1M::TYX); a.ntx = cdiv(a.W, Cout1M::TYX);
-        return launch(conv_cout1_mfma_kernel, Cout1M::NT, Cout1M::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
+        if (d->flags & PCC_CONV_IN16) return launch(conv_cout1_mfma_kernel<true>, Cout1M::NT, Cout1M::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
+        return launch(conv_cout1_mfma_kernel<false>, Cout1M::NT, Cout1M::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
     } else if (p.kind == K_COUT1) {
 #define PCC_COUT1(CI, K, S, TZ, TY, TXT)                                                                \
     if (ci == CI && k == K && s == S) {                                                                 \

@@ -255,10 +255,36 @@ PCC_API int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters
     const float* t1 = nullptr;
     int cur = 0;                 // rotating buffer that receives the next output
     int in_buf = -1, t1_buf = -1;
+    // fp16 mode: inside a SynthesisBlock whose width is 16 or 32 the two intermediate tensors (tensor1 and the output of the
+    // middle conv) live in HBM as fp16: the stride-2 transposed conv hands over in fp16 (PCC_CONV_OUT16), the two k3 stride-1
+    // convs run on conv_f16.hip (PCC_CONV_IN16), the last one adds the fp16 residual and writes fp32 for the next block.
+    int f16_block_left = 0;      // layers of the current fp16-storage block still to come
+    bool final_in16 = false;
     for (size_t i = 0; i < v.size(); ++i) {
         const LayerSpec& L = v[i];
         const bool last = i + 1 == v.size();
-        pcc_conv_desc d = layer_desc(L, im[i].cin, N, D, H, W, layer_flags | (last ? final_flags : 0));
+        int storage = 0;
+        if ((layer_flags & PCC_CONV_F16) && L.res == 1 && L.transposed && L.stride == 2 && L.k == 3 && (L.cout == 16 || L.cout == 32) &&
+            (2 * H) % 16 == 0 && (2 * W) % 16 == 0 && W % 8 == 0 && i + 2 < v.size() && v[i + 1].res == 0 && v[i + 2].res == 2 &&
+            v[i + 1].k == 3 && v[i + 1].stride == 1 && v[i + 2].k == 3 && v[i + 2].stride == 1) {
+            storage = PCC_CONV_OUT16;
+            f16_block_left = 2;
+        } else if (f16_block_left == 2) {
+            storage = PCC_CONV_IN16 | PCC_CONV_OUT16;
+            f16_block_left = 1;
+        } else if (f16_block_left == 1) {
+            storage = PCC_CONV_IN16 | PCC_CONV_RES16;
+            f16_block_left = 0;
+            // the block's output stays fp16 when its only consumer is the final 16 -> 1 transposed conv (which then reads 8 B
+            // per lane and contracts with one fp16 MFMA)
+            if (i + 2 == v.size() && v[i + 1].transposed && v[i + 1].cout == 1 && v[i + 1].k == 3 && v[i + 1].stride == 1 && L.cout == 16) {
+                storage |= PCC_CONV_OUT16;
+                final_in16 = true;
+            }
+        } else if (last && final_in16) {
+            storage = PCC_CONV_IN16;
+        }
+        pcc_conv_desc d = layer_desc(L, im[i].cin, N, D, H, W, layer_flags | storage | (last ? final_flags : 0));
         float* out;
         if (last) out = y;
         else {
