@@ -253,16 +253,6 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
                 for (int px = 0; px < 4; ++px) Ub[(j + 1) & 1][px] = ldsr(ua + (unsigned)(((dzn * 4 + pyn) * 4 + px) * 1024));
             }
-#ifdef WINO_PIN_UB
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef WINO_GROUP_UB
-            // 4 x (1 DS read, 1 MFMA), then the remaining 12 MFMAs: the reads are issued early in the MFMA shadow
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 13, 0);
-#endif
             // (2) the 16 MFMAs of this row: 4 independent accumulators, k-chained; dz = 0 opens a new output plane
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)

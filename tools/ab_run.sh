@@ -7,7 +7,7 @@ for v in "$@"; do
   echo "== $v" >> $OUT/ab.log
   IFS=';' read -ra SH <<< "$SHAPES"
   for shape in "${SH[@]}"; do
-    PCC_GEO_LIB=$PWD/build_ab/lib$v.so PCC_BENCH_IMPL=0 python tools/bench_one.py $shape 2>&1 | grep -v amdgpu.ids >> $OUT/ab.log
+    PCC_GEO_LIB=$PWD/build_ab/lib$v.so PCC_BENCH_IMPL=0 timeout 120 python tools/bench_one.py $shape 2>&1 | grep -v amdgpu.ids >> $OUT/ab.log
   done
 done
 cat $OUT/ab.log

@@ -9,7 +9,7 @@ export TMPDIR=/tmp PCC_BENCH_IMPL=0
 cd /tmp
 for v in "$@"; do
   export PCC_GEO_LIB=$R/build_ab/lib$v.so
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/$v -o p -- python $R/tools/bench_one.py $SHAPE > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/$v -o p -- timeout 180 python $R/tools/bench_one.py $SHAPE > /dev/null 2>&1
   python - <<PY
 import csv, glob, collections
 for f in glob.glob('$OUT/$v/**/*counter_collection.csv', recursive=True):

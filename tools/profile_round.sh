@@ -9,17 +9,17 @@ rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 # (1) per-kernel time of the benchmark command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 180 python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.log 2>&1
 # (2) counters of the three kernels VERDICT names, separate passes each: <key> <bench_one shape>
 pmc() {
   KEY=$1; shift
   CMD="python $R/tools/bench_one.py $*"
-  PCC_BENCH_IMPL=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$KEY/fetch -o p -- $CMD > /dev/null 2>&1
-  PCC_BENCH_IMPL=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/$KEY/write -o p -- $CMD > /dev/null 2>&1
-  PCC_BENCH_IMPL=0 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/$KEY/sq -o p -- $CMD > /dev/null 2>&1
-  PCC_BENCH_IMPL=0 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $OUT/$KEY/lds -o p -- $CMD > /dev/null 2>&1
+  PCC_BENCH_IMPL=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$KEY/fetch -o p -- timeout 180 $CMD > /dev/null 2>&1
+  PCC_BENCH_IMPL=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/$KEY/write -o p -- timeout 180 $CMD > /dev/null 2>&1
+  PCC_BENCH_IMPL=0 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/$KEY/sq -o p -- timeout 180 $CMD > /dev/null 2>&1
+  PCC_BENCH_IMPL=0 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $OUT/$KEY/lds -o p -- timeout 180 $CMD > /dev/null 2>&1
   # un-profiled duration of the same launch (HIP events inside bench_one)
-  PCC_BENCH_IMPL=0 $CMD 2>&1 | grep -v amdgpu.ids > $OUT/$KEY/time.log
+  PCC_BENCH_IMPL=0 timeout 120 $CMD 2>&1 | grep -v amdgpu.ids > $OUT/$KEY/time.log
 }
 pmc wino16 32 64 16 16 3 1 1 res
 pmc tr2g 32 32 32 16 3 2 1
