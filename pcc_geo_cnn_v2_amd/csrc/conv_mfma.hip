@@ -788,17 +788,19 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
 
     const unsigned dbg_nostore = (a.flags & 0x40000000) ? kOOB : 0u, dbg_nostage = (a.flags & 0x20000000) ? kOOB : 0u;   // profiling aids
     const bool dbg_noweights = (a.flags & 0x10000000) != 0;
-    // ---- staging items of this lane (fixed for the life of the workgroup): tile-local voxel and byte offset
-    unsigned relb[C::ITEMS];     // byte offset relative to the tile's (z-1, y-1, x-1) corner voxel, or OOB for pad slots
-    unsigned lzyx[C::ITEMS];     // lz | ly << 8 | lx << 16
+    // ---- staging items of this lane (fixed for the life of the workgroup): tile-local voxel (lz | ly << 8 | lx << 16) and
+    //      16-byte quarter q << 24 (q = 7: pad slot).  The byte offset is recomputed from them at each use (3 VALU ops) instead
+    //      of being kept in a second register array: this kernel lives at the 256-register limit of two waves per SIMD, and
+    //      every spilled value costs a scratch reload with s_waitcnt vmcnt(0) in front of the staging loads -- which drains
+    //      the weight ring and the previous group's loads.
+    unsigned lzyx[C::ITEMS];
 #pragma unroll
     for (int it = 0; it < C::ITEMS; ++it) {
         const int slot = (wave * C::ITEMS + it) * 64 + lane;
         const int u = slot / C::VSQ, q = slot - u * C::VSQ;
         const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
         const int ly = rem / C::LX, lx = rem - ly * C::LX;
-        relb[it] = (u < C::NV && q < 4) ? (unsigned)((((lz * a.H + ly) * a.W + lx) * CIN + q * 4) * 4) : kOOB;
-        lzyx[it] = (unsigned)(lz | (ly << 8) | (lx << 16));
+        lzyx[it] = (unsigned)(lz | (ly << 8) | (lx << 16)) | ((u < C::NV && q < 4) ? (unsigned)q << 24 : 7u << 24);
     }
     const unsigned in_bytes = (unsigned)a.D * a.H * a.W * CIN * 4u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -806,13 +808,16 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
     // and the sign bit IS the out-of-range offset (zeros land in LDS: SAME padding, tile overhang, pad slots)
     auto stage_group = [&](int n_, int bz0, int by0, int bx0, int g, int buf) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.in + (size_t)n_ * a.D * a.H * a.W * CIN + g * 16, in_bytes - (unsigned)g * 64u);
-        const unsigned tbase = (unsigned)((((bz0 - 1) * a.H + (by0 - 1)) * a.W + (bx0 - 1)) * CIN * 4);
+        const int HWc = a.H * a.W * CIN * 4, Wc = a.W * CIN * 4;
 #pragma unroll
         for (int it = 0; it < C::ITEMS; ++it) {
-            const int gz = bz0 - 1 + (int)(lzyx[it] & 0xFF), gy = by0 - 1 + (int)((lzyx[it] >> 8) & 0xFF), gx = bx0 - 1 + (int)(lzyx[it] >> 16);
-            const unsigned neg = (unsigned)(gz | (a.D - 1 - gz) | gy | (a.H - 1 - gy) | gx | (a.W - 1 - gx)) & kOOB;
+            const int lz = (int)(lzyx[it] & 0xFF), ly = (int)((lzyx[it] >> 8) & 0xFF), lx = (int)((lzyx[it] >> 16) & 0xFF), q = (int)(lzyx[it] >> 24);
+            const int gz = bz0 - 1 + lz, gy = by0 - 1 + ly, gx = bx0 - 1 + lx;
+            const unsigned neg = ((unsigned)(gz | (a.D - 1 - gz) | gy | (a.H - 1 - gy) | gx | (a.W - 1 - gx)) & kOOB) | (q == 7 ? kOOB : 0u);
+            // absolute offset from the tile-dependent coordinates (nothing loop-invariant to hoist into registers)
+            const unsigned off = (unsigned)(gz * HWc + gy * Wc + gx * (CIN * 4) + q * 16);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr)((char*)lds + buf * C::BUF_BYTES + (wave * C::ITEMS + it) * 1024), 16,
-                                                     (int)((tbase + relb[it]) | neg | dbg_nostage), 0, 0, 0);
+                                                     (int)(off | neg | dbg_nostage), 0, 0, 0);
         }
     };
     auto decode = [&](int t, int& n_, int& bz0, int& by0, int& bx0) {
@@ -857,15 +862,20 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
         // per-row output offsets of this tile (the epilogue of a parity class runs inside the last group, right after the
         // class's taps: the 8 x R x CTW stores of a tile are spread over that group instead of bursting at its end)
         const int gzb = bz0 + w_z, gxb = bx0 + lx0;
-        unsigned ooff[R], roff[R];
+        unsigned ooff[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int gyb = by0 + ly0 + i * C::RY;
             const bool ok = gzb < a.D && gyb < a.H && gxb < a.W;
             const unsigned vox = (unsigned)((2 * gzb * a.OH + 2 * gyb) * a.OW + 2 * gxb);
             ooff[i] = ok ? (vox * (unsigned)a.ocs + (unsigned)a.oco + cq * 4) * 4u : kOOB;
-            roff[i] = ok ? (vox * (unsigned)COUT + cq * 4) * 4u : kOOB;
         }
+        // residual offset of row i (no layer of the c* graphs adds a residual to a stride-2 transposed conv: computed on demand)
+        auto roff_of = [&](int i) -> unsigned {
+            const int gyb = by0 + ly0 + i * C::RY;
+            const bool ok = gzb < a.D && gyb < a.H && gxb < a.W;
+            return ok ? ((unsigned)((2 * gzb * a.OH + 2 * gyb) * a.OW + 2 * gxb) * (unsigned)COUT + cq * 4) * 4u : kOOB;
+        };
 #pragma unroll 1
         for (int g = 0; g < C::NG; ++g) {
             // group g has landed in LDS (this wave's loads: vmcnt; the other waves': barrier); nobody reads the other buffer any more
@@ -934,7 +944,7 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
                         f32x4 o = acc[cls][i][ct] + bias4[ct];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], relu_lo);
-                        if (has_res) o += buf_load4(rres, roff[i], (unsigned)((ct0 + ct) * 64));      // (wave-uniform branch; no layer of the c* graphs takes it)
+                        if (has_res) o += buf_load4(rres, roff_of(i), (unsigned)((ct0 + ct) * 64));      // (wave-uniform branch; no layer of the c* graphs takes it)
                         if (a.flags & PCC_CONV_CLIP01) {                                                // (wave-uniform, ditto)
 #pragma unroll
                             for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
