@@ -42,8 +42,15 @@ def decompress(args):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         import torch.distributed as dist
+        # PCC_DIST_BACKEND=gloo + PCC_DIST_SAME_GPU=1: every rank on GPU 0 with host-side collectives -- lets a 1-GPU box run the
+        # sharded path end to end (tests/test_cli_gpu.py); the default is one GPU per rank over RCCL
+        if os.environ.get('PCC_DIST_SAME_GPU'):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if os.environ.get('PCC_DIST_BACKEND', 'nccl') == 'gloo':
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     rank, world = sharding.world_info()
     assert not (args.debug and world > 1), '--debug checks every intermediate of every block: run it on one GPU'
     sess = ops.get_context(torch.device('cuda', local_rank))

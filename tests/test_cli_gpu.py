@@ -62,3 +62,40 @@ def test_cli_missing_checkpoint_fails_like_reference(tmp_path):
                         '--resolution', '64', '--octree_level', '1', '--opt_metrics', 'd1_mse'], cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT),
                        capture_output=True, text=True)
     assert p.returncode != 0 and 'was not found' in p.stderr
+
+
+def test_cli_sharded_over_two_ranks_writes_the_single_process_file(tmp_path):
+    """compress_octree / decompress_octree under torch.distributed.run with two ranks (both on this box's one GPU, gloo
+    collectives): rank 0 writes byte-identical .ply.bin / .enc.metric.json / decoded .ply to the single-process run
+    (contiguous Morton ranges per rank, one gather at the end)."""
+    res, level = 128, 2   # 64 blocks of 32^3
+    pts = _cloud(res, 3)
+    src = str(tmp_path / 'in.ply')
+    pc_io.write_df(src, pc_io.pa_to_df(pts))
+    ck = str(tmp_path / 'ckpt')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.run([sys.executable, '-m', 'pcc_geo_cnn_v2_amd.init_checkpoint', '--model_config', 'c3p', '--checkpoint_dir', ck],
+                   cwd=ROOT, env=env, check=True, capture_output=True)
+
+    def run(tag, nranks):
+        out, dec_enc, dec = str(tmp_path / f'{tag}.ply.bin'), str(tmp_path / f'{tag}.enc.ply'), str(tmp_path / f'{tag}.dec.ply')
+        launcher = [sys.executable, '-m'] if nranks == 1 else \
+            [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nranks}', '--master-addr', '127.0.0.1',
+             '--master-port', '29533', '-m']
+        e = dict(env, PCC_DIST_BACKEND='gloo', PCC_DIST_SAME_GPU='1')
+        for args in (['pcc_geo_cnn_v2_amd.compress_octree', '--input_files', src, '--output_files', out, '--dec_files', dec_enc,
+                      '--checkpoint_dir', ck, '--model_config', 'c3p', '--resolution', str(res), '--octree_level', str(level),
+                      '--opt_metrics', 'd1_mse', '--batch_size', '7'],
+                     ['pcc_geo_cnn_v2_amd.decompress_octree', '--input_files', out, '--output_files', dec, '--checkpoint_dir', ck,
+                      '--model_config', 'c3p', '--batch_size', '5']):
+            p = subprocess.run(launcher + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-3000:]
+        return out, dec_enc, dec
+
+    a, b = run('one', 1), run('two', 2)
+    with gzip.open(a[0], 'rb') as f1, gzip.open(b[0], 'rb') as f2:
+        assert f1.read() == f2.read()                               # the same container, byte for byte (adaptive thresholds included)
+    assert json.load(open(a[0] + '.enc.metric.json')) == json.load(open(b[0] + '.enc.metric.json'))
+    for i in (1, 2):
+        assert np.array_equal(pc_io.load_pc(a[i]), pc_io.load_pc(b[i]))
+    assert np.array_equal(pc_io.load_pc(b[1]), pc_io.load_pc(b[2]))   # decoder == encoder-side reconstruction
