@@ -115,11 +115,11 @@ class CompressionModel:
 
     # ------------------------------------------------------------------ helpers
     def _ctx(self, sess):
-        ctx = sess if isinstance(sess, ops.Context) else ops.get_context(None)
-        # BASELINE.json configs[4]: fp16 MFMA on the direct conv kernels.  Encoder and decoder must agree on it (the
-        # decoder recomputes sigma_hat): like the checkpoint, it is part of the codec configuration, not of the stream.
-        ctx.conv_flags = L.PCC_CONV_F16 if self.precision == 'fp16' else 0
-        return ctx
+        ctx = sess if isinstance(sess, (ops.Context, ops._ContextView)) else ops.get_context(None)
+        # BASELINE.json configs[4]: the fp16 mode.  Encoder and decoder must agree on it (the decoder recomputes sigma_hat):
+        # like the checkpoint, it is part of the codec configuration, not of the stream.  A VIEW of the context carries the
+        # flag: the caller's context is not modified.
+        return ctx.view(L.PCC_CONV_F16 if self.precision == 'fp16' else 0)
 
     def _dev(self, ctx, name, arr):
         key = (ctx.device.index, name)

@@ -39,6 +39,18 @@ class Context:
             self._ws = ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
         return ws
 
+    conv_flags = 0      # extra pcc_conv_desc.flags of every conv issued through this context (0 = the reference's fp32)
+
+    def view(self, conv_flags):
+        """The same context (handle, device, stream, workspace) with other default conv flags -- how a model in the fp16 mode
+        (PCC_CONV_F16) uses a context without changing it for anybody else."""
+        if not conv_flags:
+            return self
+        views = self.__dict__.setdefault('_views', {})
+        if conv_flags not in views:
+            views[conv_flags] = _ContextView(self, conv_flags)
+        return views[conv_flags]
+
     def close(self):
         if self.handle is not None:
             L.lib().pcc_ctx_destroy(self.handle)
@@ -49,6 +61,17 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class _ContextView:
+    def __init__(self, base, conv_flags):
+        self._base, self.conv_flags = base, conv_flags
+
+    def __getattr__(self, name):          # handle, device, num_cu, stream, workspace, ...
+        return getattr(self._base, name)
+
+    def view(self, conv_flags):
+        return self._base.view(conv_flags)
 
 
 _CONTEXTS = {}

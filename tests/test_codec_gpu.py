@@ -89,8 +89,9 @@ def test_block_path_matches_oracle(ctx, oracle, name, res, backend, data_format)
     print(f'{name}@{res} {data_format}: boundary flips (symbols, indexes) per block {flips}')
 
 
-@pytest.mark.parametrize('name,res,nb', [('c3p', 64, 5), ('c1', 64, 3), ('c2', 32, 4), ('c3', 32, 4)])
-def test_compress_decompress_blocks_roundtrip(ctx, name, res, nb):
+@pytest.mark.parametrize('name,res,nb,precision', [('c3p', 64, 5, 'fp32'), ('c1', 64, 3, 'fp32'), ('c2', 32, 4, 'fp32'), ('c3', 32, 4, 'fp32'),
+                                                   ('c3p', 64, 5, 'fp16'), ('c3', 64, 3, 'fp16'), ('c1', 64, 2, 'fp16')])
+def test_compress_decompress_blocks_roundtrip(ctx, name, res, nb, precision):
     """encode -> decode on the GPU: decoded point lists are bit-identical to the encoder-side ones
     (the reference's own self-check, ev_experiment.py:157-162 / decompress_octree.py --debug)."""
     from pcc_geo_cnn_v2_amd.utils.octree_coding import partition_octree
@@ -101,12 +102,12 @@ def test_compress_decompress_blocks_roundtrip(ctx, name, res, nb):
     # place the blocks in distinct octants of a (2 res)^3 cloud
     pts = np.vstack([b + np.array([(i & 1), (i >> 1) & 1, (i >> 2) & 1]) * res for i, b in enumerate(blocks8)])
     blocks, binstr = partition_octree(pts, [0, 0, 0], [R] * 3, level)
-    enc = ModelConfigType[name].build(batch_size=2)
+    enc = ModelConfigType[name].build(batch_size=2, precision=precision)
     enc.compress([1, 1, res, res, res])
     enc.set_weights(scaled_weights(enc, 2.2))
     data_list, metadata, dbg_e = enc.compress_blocks(ctx, blocks, binstr, pts, R, level, fixed_threshold=True, debug=True)
     assert len(data_list) == 1 and len(data_list[0]) == len(blocks)
-    dec = ModelConfigType[name].build(batch_size=3)   # different chunking on purpose
+    dec = ModelConfigType[name].build(batch_size=3, precision=precision)   # different chunking on purpose
     dec.decompress()
     w = enc.get_weights()
     dec.set_weights({k: v for k, v in w.items() if not k.startswith(('analysis/', 'hyper_analysis/'))})
