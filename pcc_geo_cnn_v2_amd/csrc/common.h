@@ -12,7 +12,12 @@ struct pcc_ctx {
     int num_cu;
     hipDeviceProp_t prop;
     void* profile = nullptr;     // live kernel timing state of network.hip (pcc_profile_select / pcc_profile_read)
+    // Device scratch owned by the context (grown on demand, freed with it): the partial sums of the 64-channel fp16 layers
+    // (conv_f16.hip).  One tensor per context: launches that use it must be ordered on one stream.
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
 };
+int pcc_ctx_scratch(pcc_ctx* ctx, size_t bytes, void** ptr);
 void pcc_profile_free(pcc_ctx* ctx);
 
 void pcc_set_error(const char* fmt, ...);

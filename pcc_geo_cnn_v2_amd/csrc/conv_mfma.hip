@@ -1560,7 +1560,7 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
             // 16->16 / 32->32 k3 stride-1 layers also carry the Winograd-transformed weights (conv_wino.hip)
             if (pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && d->stride == 1)
                 return k3 * d->Cin * d->Cout + (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_U_FLOATS +
-                       (d->Cin <= 32 ? pcc_f16_packed_bytes(d->Cin) / 4 : 0);     // + the fp16 fragments of conv_f16.hip
+                       pcc_f16_packed_bytes(d->Cin) / 4;     // + the fp16 fragments of conv_f16.hip
             return k3 * d->Cin * d->Cout;
         case K_TR2: return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1);     // k3: second copy in the order of conv_tr2g_kernel
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
@@ -1608,7 +1608,7 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                                 s += G[py][ky] * G[px][kx] * (double)Wf(kz, ky, kx, 16 * cig + 4 * (lane >> 4) + kk, 16 * cog + (lane & 15));
                             u[(((size_t)(cig * NCT + cog) * 48 + (kz * 4 + py) * 4 + px) * 64 + lane) * 4 + kk] = (float)s;
                         }
-            if (Cin <= 32) {      // fp16 fragment image of conv_f16.hip behind the Winograd block
+            {      // fp16 fragment image of conv_f16.hip behind the Winograd block
                 float* wlog = (float*)malloc((size_t)27 * Cin * Cout * sizeof(float));
                 PCC_REQUIRE(wlog != nullptr, "pcc_conv_pack_weights: out of memory");
                 for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
@@ -1690,7 +1690,7 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
     if ((d->flags & (PCC_CONV_IN16 | PCC_CONV_RES16)) && p.kind != K_COUT1M) {
         // fp16-storage layer (conv_f16.hip): fp16 input (and residual), fp16 or fp32 output
         PCC_REQUIRE(p.kind == K_FWD && (d->flags & PCC_CONV_IN16) && pcc_f16_eligible(d),
-                    "pcc_conv3d: PCC_CONV_IN16 covers k3 stride-1 layers with Cin = Cout in {16, 32} (H, W multiples of 16) and the 16 -> 1 transposed layer");
+                    "pcc_conv3d: PCC_CONV_IN16 covers k3 stride-1 layers with Cin = Cout in {16, 32, 64} (H, W multiples of 16) and the 16 -> 1 transposed layer");
         const float* f16w = w_packed + (size_t)27 * ci * co + (size_t)(ci / 16) * (co / 16) * PCC_WINO_U_FLOATS;
         return pcc_conv_f16(ctx, d, in, f16w, bias, residual, out, !(d->flags & PCC_CONV_OUT16), st);
     }

@@ -46,8 +46,20 @@ PCC_API int pcc_ctx_create(int device, pcc_ctx** out) {
     return PCC_OK;
 }
 
+int pcc_ctx_scratch(pcc_ctx* ctx, size_t bytes, void** ptr) {
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) PCC_CHECK_HIP(hipFree(ctx->scratch));      // hipFree waits for the kernels that still use it
+        ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+        PCC_CHECK_HIP(hipMalloc(&ctx->scratch, bytes));
+        ctx->scratch_bytes = bytes;
+    }
+    *ptr = ctx->scratch;
+    return PCC_OK;
+}
+
 PCC_API int pcc_ctx_destroy(pcc_ctx* ctx) {
     if (ctx) pcc_profile_free(ctx);
+    if (ctx && ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
     return PCC_OK;
 }

@@ -323,7 +323,7 @@ def profile_read(ctx, cap=8192):
 
 def conv3d_fp16_storage(ctx, x, layer, residual=None, in16=None, out16=True, flags=0):
     """One layer of the fp16 mode with fp16 tensors in HBM (PCC_CONV_IN16 / OUT16 / RES16, include/pcc_geo.h): x fp16 (k3
-    stride-1 layers, Cin = Cout in {16, 32}) or fp32 (k3 stride-2 transposed layers, out16 only).  pcc_network_forward chains
+    stride-1 layers, Cin = Cout in {16, 32, 64}) or fp32 (k3 stride-2 transposed layers, out16 only).  pcc_network_forward chains
     these itself in the fp16 mode; this wrapper exists for tests and for callers that chain layers by hand."""
     in16 = (x.dtype == torch.float16) if in16 is None else in16
     assert x.is_contiguous() and x.device == ctx.device and x.dim() == 5 and x.dtype == (torch.float16 if in16 else torch.float32)

@@ -223,6 +223,9 @@ F16S_CASES = [  # C, N, D, H, W, transposed, residual, out16
     (16, 2, 5, 16, 16, True, False, True), (16, 1, 9, 32, 48, False, True, True), (16, 2, 6, 16, 32, True, True, False),
     (32, 1, 5, 16, 16, True, False, True), (32, 2, 7, 32, 16, False, True, False), (16, 3, 32, 32, 32, True, True, True),
     (32, 2, 32, 32, 32, True, True, True), (16, 1, 1, 16, 16, False, False, True), (32, 1, 2, 48, 32, True, True, True),
+    # C = 64: two input-half launches of the 32-channel kernel, fp16 partial sums between them
+    (64, 1, 5, 16, 16, True, False, True), (64, 2, 16, 16, 16, True, True, False), (64, 1, 7, 32, 16, False, True, True),
+    (64, 2, 32, 32, 32, True, True, False), (64, 1, 1, 16, 32, False, False, False),
 ]
 
 
@@ -231,7 +234,8 @@ def test_fp16_storage_conv_matches_oracle(ctx, case):
     """conv_f16.hip (PCC_CONV_IN16 / OUT16 / RES16: fp16 activations in HBM, v_mfma_f32_16x16x32_f16, fp32 accumulate) -- the
     k3 stride-1 layers of the blocks of /root/reference/src/model_transforms.py:62-81 in the fp16 mode (BASELINE.json configs[4]).
     Against the oneDNN restatement on the SAME fp16-rounded operands the only error left is the accumulation order (fp32 output:
-    1e-5) plus the output rounding (fp16 output: 2^-11 relative); against unrounded operands the stated fp16 tolerance 4e-3."""
+    1e-5) plus the output rounding (fp16 output, and the fp16 partial sums of C = 64: 2^-11 relative); against unrounded operands
+    the stated fp16 tolerance 4e-3."""
     from oracle import torch_oracle as T
     C, N, D, H, W, tr, res, out16 = case
     rng = np.random.default_rng(C + N + D)
@@ -250,7 +254,7 @@ def test_fp16_storage_conv_matches_oracle(ctx, case):
     ref = conv(x32, w, b, 1, True) + (torch.from_numpy(r32) if res else 0)
     g = got.float().cpu()
     scale = 1 + ref.abs().max().item()
-    assert (g - ref_q).abs().max().item() <= (6e-4 if out16 else 1e-5) * scale
+    assert (g - ref_q).abs().max().item() <= (6e-4 if out16 or C == 64 else 1e-5) * scale
     assert (g - ref).abs().max().item() <= TOL_F16 * scale
 
 
