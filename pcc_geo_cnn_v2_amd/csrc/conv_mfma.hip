@@ -19,6 +19,8 @@
 //   conv_cin1_kernel: Conv3D with Cin = 1 (first layer): k-slots of the MFMA are kernel taps along x.
 //   conv_cout1_kernel: Conv3DTranspose with Cout = 1 (last layer): VALU dot products from an LDS tile.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -763,8 +765,33 @@ struct Tr2gCfg {
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
 };
 
-template <int CIN, int COUT, int TX, int TZ, int TY, int TXT, int R, int CTW, bool F16 = false, int WPE = 2>
-__global__ void __launch_bounds__((Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>::NT), WPE)   // WPE waves per SIMD: <= 512 / WPE registers
+// tap seq (0..26) of the parity-class order [class (pz,py,px)][kz][ky][kx]: its class, input offsets (0 / -1 per dim), and
+// whether it is the first / last tap of its class.  Evaluated at compile time (seq is a constant of the unrolled loops).
+struct Tr2gTap { int cls, dz, dy, dx; bool first, last; };
+__host__ __device__ constexpr Tr2gTap tr2g_tap(int want) {
+    int seq = 0;
+    for (int cls = 0; cls < 8; ++cls) {
+        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+        const int ntap = (pz ? 1 : 2) * (py ? 1 : 2) * (px ? 1 : 2);      // even outputs take taps 0 and 2, odd ones tap 1
+        int t = 0;
+        for (int kz = pz; kz < 3; kz += 2)
+            for (int ky = py; ky < 3; ky += 2)
+                for (int kx = px; kx < 3; kx += 2, ++seq, ++t)
+                    if (seq == want) return Tr2gTap{cls, (pz - kz) / 2, (py - ky) / 2, (px - kx) / 2, t == 0, t == ntap - 1};
+    }
+    return Tr2gTap{0, 0, 0, 0, false, false};
+}
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+// EPI: the epilogue is compiled for the layer's flags (the per-store flag tests of a generic epilogue cost this kernel more
+// scalar registers and branches than it has to spare): 0 = bias / ReLU, fp32 store (every stride-2 transposed layer of the c*
+// graphs); 1 = bias / ReLU, fp16 store (PCC_CONV_OUT16, the fp16 mode); 2 = any flags (residual, clip), tested at run time.
+enum { TR2G_EPI_F32 = 0, TR2G_EPI_F16 = 1, TR2G_EPI_ANY = 2 };
+
+template <int CIN, int COUT, int TX, int TZ, int TY, int TXT, int R, int CTW, bool F16 = false, int EPI = TR2G_EPI_F32>
+__global__ void __launch_bounds__((Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>::NT), 2)   // two waves per SIMD: <= 256 registers
 conv_tr2g_kernel(ConvArgs a, int ntiles) {
     using C = Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>;
     static_assert(C::NG % 2 == 0, "the LDS double buffer alternates per cin group across tiles");
@@ -786,38 +813,40 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
     const int lane_off = (((w_z + 1) * C::LY + ly0 + 1) * C::LX + lx0 + 1) * C::VS + cq * 4;
     constexpr int ROW_OFF = C::RY * C::LX * C::VS;
 
-    const unsigned dbg_nostore = (a.flags & 0x40000000) ? kOOB : 0u, dbg_nostage = (a.flags & 0x20000000) ? kOOB : 0u;   // profiling aids
-    const bool dbg_noweights = (a.flags & 0x10000000) != 0;
-    // ---- staging items of this lane (fixed for the life of the workgroup): tile-local voxel (lz | ly << 8 | lx << 16) and
-    //      16-byte quarter q << 24 (q = 7: pad slot).  The byte offset is recomputed from them at each use (3 VALU ops) instead
-    //      of being kept in a second register array: this kernel lives at the 256-register limit of two waves per SIMD, and
-    //      every spilled value costs a scratch reload with s_waitcnt vmcnt(0) in front of the staging loads -- which drains
-    //      the weight ring and the previous group's loads.
-    unsigned lzyx[C::ITEMS];
-#pragma unroll
-    for (int it = 0; it < C::ITEMS; ++it) {
-        const int slot = (wave * C::ITEMS + it) * 64 + lane;
-        const int u = slot / C::VSQ, q = slot - u * C::VSQ;
-        const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
-        const int ly = rem / C::LX, lx = rem - ly * C::LX;
-        lzyx[it] = (unsigned)(lz | (ly << 8) | (lx << 16)) | ((u < C::NV && q < 4) ? (unsigned)q << 24 : 7u << 24);
-    }
-    const unsigned in_bytes = (unsigned)a.D * a.H * a.W * CIN * 4u;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    // global -> LDS of cin group g of tile (n, bz0, by0, bx0); pure-VALU range test: a negative term sets the sign bit,
-    // and the sign bit IS the out-of-range offset (zeros land in LDS: SAME padding, tile overhang, pad slots)
-    auto stage_group = [&](int n_, int bz0, int by0, int bx0, int g, int buf) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.in + (size_t)n_ * a.D * a.H * a.W * CIN + g * 16, in_bytes - (unsigned)g * 64u);
+    // ---- staging items of this lane (fixed for the life of the workgroup): the tile-local voxel packed in 10-bit fields
+    //      (lz | ly << 10 | lx << 20; pad slots carry an lz that fails every range test) and its byte offset relative to the
+    //      tile's first haloed voxel.  Per tile the range test of all three dims is two packed adds: with a bias of 512 per
+    //      field, bit 9 of (p + lo) says g >= 0 and bit 9 of (hi - p) says g <= dim - 1 (fields neither carry nor borrow:
+    //      coordinates and dims stay below 256 -- the launcher checks).
+    unsigned pk[C::ITEMS], rel[C::ITEMS];
+    {
         const int HWc = a.H * a.W * CIN * 4, Wc = a.W * CIN * 4;
 #pragma unroll
         for (int it = 0; it < C::ITEMS; ++it) {
-            const int lz = (int)(lzyx[it] & 0xFF), ly = (int)((lzyx[it] >> 8) & 0xFF), lx = (int)((lzyx[it] >> 16) & 0xFF), q = (int)(lzyx[it] >> 24);
-            const int gz = bz0 - 1 + lz, gy = by0 - 1 + ly, gx = bx0 - 1 + lx;
-            const unsigned neg = ((unsigned)(gz | (a.D - 1 - gz) | gy | (a.H - 1 - gy) | gx | (a.W - 1 - gx)) & kOOB) | (q == 7 ? kOOB : 0u);
-            // absolute offset from the tile-dependent coordinates (nothing loop-invariant to hoist into registers)
-            const unsigned off = (unsigned)(gz * HWc + gy * Wc + gx * (CIN * 4) + q * 16);
+            const int slot = (wave * C::ITEMS + it) * 64 + lane;
+            const int u = slot / C::VSQ, q = slot - u * C::VSQ;
+            const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
+            const int ly = rem / C::LX, lx = rem - ly * C::LX;
+            const bool data = u < C::NV && q < 4;
+            pk[it] = data ? (unsigned)(lz | (ly << 10) | (lx << 20)) : 511u;
+            rel[it] = data ? (unsigned)(lz * HWc + ly * Wc + lx * (CIN * 4) + q * 16) : 0u;
+        }
+    }
+    constexpr unsigned kBit9 = (1u << 9) | (1u << 19) | (1u << 29);
+    const unsigned in_bytes = (unsigned)a.D * a.H * a.W * CIN * 4u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // global -> LDS of cin group g of tile (n, bz0, by0, bx0): zeros land in LDS for SAME padding, tile overhang, pad slots
+    auto stage_group = [&](int n_, int bz0, int by0, int bx0, int g, int buf) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.in + (size_t)n_ * a.D * a.H * a.W * CIN + g * 16, in_bytes - (unsigned)g * 64u);
+        const int HWc = a.H * a.W * CIN * 4, Wc = a.W * CIN * 4;
+        const unsigned lo = (unsigned)((bz0 - 1 + 512) | ((by0 - 1 + 512) << 10) | ((bx0 - 1 + 512) << 20));
+        const unsigned hi = (unsigned)((a.D - bz0 + 512) | ((a.H - by0 + 512) << 10) | ((a.W - bx0 + 512) << 20));
+        const unsigned base = (unsigned)((bz0 - 1) * HWc + (by0 - 1) * Wc + (bx0 - 1) * (CIN * 4));     // (may wrap below 0: rel brings it back)
+#pragma unroll
+        for (int it = 0; it < C::ITEMS; ++it) {
+            const bool ok = (((pk[it] + lo) & (hi - pk[it])) & kBit9) == kBit9;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr)((char*)lds + buf * C::BUF_BYTES + (wave * C::ITEMS + it) * 1024), 16,
-                                                     (int)(off | neg | dbg_nostage), 0, 0, 0);
+                                                     (int)(ok ? base + rel[it] : kOOB), 0, 0, 0);
         }
     };
     auto decode = [&](int t, int& n_, int& bz0, int& by0, int& bx0) {
@@ -840,12 +869,15 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
     static_assert(NSEQ % RING == 0, "the weight ring position must repeat per group");
     f32x4 wf[RING][CTW];
     const size_t ovox_n = (size_t)a.OD * a.OH * a.OW;
-    const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
+    const bool any_res = EPI == TR2G_EPI_ANY && (a.flags & PCC_CONV_ADD) != 0;
+    const bool any_out16 = EPI == TR2G_EPI_ANY && (a.flags & PCC_CONV_OUT16) != 0;
+    const bool out16 = EPI == TR2G_EPI_F16 || any_out16;
     const float relu_lo = (a.flags & PCC_CONV_RELU) ? 0.f : -__builtin_inff();
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 bias4[CTW];
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct)
-        bias4[ct] = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + (ct0 + ct) * 16 + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bias4[ct] = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + (ct0 + ct) * 16 + cq * 4) : zero4;
 
     f32x4 acc[8][R][CTW];
 #pragma unroll 1
@@ -859,109 +891,108 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
         for (int r = 0; r < RING - 1; ++r)
 #pragma unroll
             for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct0 + ct) * 1024u);
-        // per-row output offsets of this tile (the epilogue of a parity class runs inside the last group, right after the
-        // class's taps: the 8 x R x CTW stores of a tile are spread over that group instead of bursting at its end)
+        // per-row output BYTE offsets of this tile for class (0,0,0) (the epilogue of a parity class runs inside the last
+        // group, right after the class's taps: the 8 x R x CTW stores of a tile are spread over that group instead of bursting
+        // at its end).  One descriptor per tile (image n); the class adds a wave-uniform offset.  kOOB plus those offsets
+        // stays beyond the descriptor's range (the launcher admits images below 2^31 bytes only).
         const int gzb = bz0 + w_z, gxb = bx0 + lx0;
+        const unsigned esz = out16 ? 2u : 4u;
         unsigned ooff[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int gyb = by0 + ly0 + i * C::RY;
             const bool ok = gzb < a.D && gyb < a.H && gxb < a.W;
             const unsigned vox = (unsigned)((2 * gzb * a.OH + 2 * gyb) * a.OW + 2 * gxb);
-            ooff[i] = ok ? (vox * (unsigned)a.ocs + (unsigned)a.oco + cq * 4) * 4u : kOOB;
+            ooff[i] = ok ? (vox * (unsigned)a.ocs + (unsigned)a.oco + cq * 4) * esz : kOOB;
         }
-        // residual offset of row i (no layer of the c* graphs adds a residual to a stride-2 transposed conv: computed on demand)
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc((const char*)a.out + (size_t)n * ovox_n * a.ocs * esz, (unsigned)(ovox_n * a.ocs * esz));
+        // residual (EPI_ANY only; no layer of the c* graphs adds one to a stride-2 transposed conv): offsets computed on demand
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(any_res ? a.res + (size_t)n * ovox_n * COUT : a.in, any_res ? (unsigned)(ovox_n * COUT * 4) : 0u);
         auto roff_of = [&](int i) -> unsigned {
             const int gyb = by0 + ly0 + i * C::RY;
             const bool ok = gzb < a.D && gyb < a.H && gxb < a.W;
             return ok ? ((unsigned)((2 * gzb * a.OH + 2 * gyb) * a.OW + 2 * gxb) * (unsigned)COUT + cq * 4) * 4u : kOOB;
         };
-#pragma unroll 1
-        for (int g = 0; g < C::NG; ++g) {
+
+        // one cin group of the tile.  FIRST: the accumulators start from 0 (srcC = inline 0, no zero-init pass);
+        // LAST: each parity class is finished and stored right after its taps.
+        auto group = [&](auto first_tag, auto last_tag, int g) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
             // group g has landed in LDS (this wave's loads: vmcnt; the other waves': barrier); nobody reads the other buffer any more
             __builtin_amdgcn_s_waitcnt(0x0F70 | ((RING - 1) * CTW));    // vmcnt(weights still in flight) expcnt(7) lgkmcnt(15)
             __syncthreads();
-            if (g + 1 < C::NG) stage_group(n, bz0, by0, bx0, g + 1, (g + 1) & 1);
+            if (!LAST) stage_group(n, bz0, by0, bx0, g + 1, (g + 1) & 1);
             else if (has_next) stage_group(nn, nbz0, nby0, nbx0, 0, 0);          // next tile's first group under this tile's last
             const float* lbase = lds + (g & 1) * (C::BUF_BYTES / 4) + lane_off;
             const unsigned wg_off = (unsigned)(g * NSEQ * C::NCT) * 1024u;
-            int seq = 0;  // compile-time after unrolling
+            // B operands are read one tap ahead (double buffer): the LDS latency of tap t + 1 runs under the MFMAs of tap t
+            f32x4 b[2][R];
 #pragma unroll
-            for (int cls = 0; cls < 8; ++cls) {
-                const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
-                bool first = true;      // first tap of the class: group 0 starts the accumulators from 0 (no zero-init pass)
-#pragma unroll
-                for (int kz = pz; kz < 3; kz += 2)
-#pragma unroll
-                    for (int ky = py; ky < 3; ky += 2)
-#pragma unroll
-                        for (int kx = px; kx < 3; kx += 2, ++seq) {
-                            const int dz = (pz - kz) / 2, dy = (py - ky) / 2, dx = (px - kx) / 2;      // 0 or -1
-                            const int toff = ((dz * C::LY + dy) * C::LX + dx) * C::VS;
-                            if (!dbg_noweights) {   // weights two taps ahead (runs into the next group's first taps; past the end: zeros)
-#pragma unroll
-                                for (int ct = 0; ct < CTW; ++ct)
-                                    wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, wg_off + (unsigned)((seq + RING - 1) * C::NCT + ct0 + ct) * 1024u);
-                                PCC_PIN_VMEM();
-                            }
-                            f32x4 b[R];
-#pragma unroll
-                            for (int i = 0; i < R; ++i) b[i] = *reinterpret_cast<const f32x4*>(lbase + toff + i * ROW_OFF);
-                            if (first) {
-#pragma unroll
-                                for (int i = 0; i < R; ++i)
-#pragma unroll
-                                    for (int ct = 0; ct < CTW; ++ct)
-                                        if (g == 0) acc[cls][i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            }
-                            first = false;
-                            if constexpr (F16) {
-#pragma unroll
-                                for (int i = 0; i < R; ++i)
-#pragma unroll
-                                    for (int ct = 0; ct < CTW; ++ct) acc[cls][i][ct] = mfma16h(wf[seq % RING][ct], b[i], acc[cls][i][ct]);
-                            } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                                for (int i = 0; i < R; ++i)
-#pragma unroll
-                                    for (int ct = 0; ct < CTW; ++ct)
-                                        acc[cls][i][ct] = mfma16(wf[seq % RING][ct][j], b[i][j], acc[cls][i][ct]);
-                            }
-                        }
-                if (g == C::NG - 1) {      // (wave-uniform) this class is complete: bias / ReLU / residual / clip, stores
-                const size_t cvox = ((size_t)pz * a.OH + py) * a.OW + px;
-                const bool out16 = (a.flags & PCC_CONV_OUT16) != 0;       // (wave-uniform) fp16 hand-over to conv_f16.hip
-                const __amdgpu_buffer_rsrc_t rout = out16
-                    ? make_rsrc((const unsigned short*)a.out + ((size_t)n * ovox_n + cvox) * a.ocs, (unsigned)((ovox_n - cvox) * a.ocs * 2))
-                    : make_rsrc(a.out + ((size_t)n * ovox_n + cvox) * a.ocs, (unsigned)((ovox_n - cvox) * a.ocs * 4));
-                const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + ((size_t)n * ovox_n + cvox) * COUT : a.in, has_res ? (unsigned)((ovox_n - cvox) * COUT * 4) : 0u);
+            for (int i = 0; i < R; ++i) b[0][i] = *reinterpret_cast<const f32x4*>(lbase + i * ROW_OFF);       // tap 0: class (0,0,0), no offset
+            static_for(std::make_integer_sequence<int, NSEQ>{}, [&](auto seq_tag) __attribute__((always_inline)) {
+                constexpr int seq = decltype(seq_tag)::value;
+                constexpr Tr2gTap T = tr2g_tap(seq);
+                constexpr Tr2gTap Tn = tr2g_tap(seq + 1 < NSEQ ? seq + 1 : seq);
+                constexpr int next_off = ((Tn.dz * C::LY + Tn.dy) * C::LX + Tn.dx) * C::VS;
+                constexpr int cls = T.cls;
+                // weights RING - 1 taps ahead (runs into the next group's first taps; past the end: zeros)
 #pragma unroll
                 for (int ct = 0; ct < CTW; ++ct)
+                    wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, wg_off + (unsigned)((seq + RING - 1) * C::NCT + ct0 + ct) * 1024u);
+                if constexpr (seq + 1 < NSEQ) {
 #pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        f32x4 o = acc[cls][i][ct] + bias4[ct];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], relu_lo);
-                        if (has_res) o += buf_load4(rres, roff_of(i), (unsigned)((ct0 + ct) * 64));      // (wave-uniform branch; no layer of the c* graphs takes it)
-                        if (a.flags & PCC_CONV_CLIP01) {                                                // (wave-uniform, ditto)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
-                        }
-                        // immediate soffset: the compiler guards the store-data hazard of this form (see conv_wino.hip)
-                        if (out16) {
-                            h16x4 oh;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) oh[c] = (_Float16)o[c];
-                            const unsigned off = ooff[i] == kOOB ? kOOB : (ooff[i] + (unsigned)((ct0 + ct) * 64)) >> 1;
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oh), rout, (int)(off | dbg_nostore), 0, 0);
-                        } else
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)((ooff[i] + (unsigned)((ct0 + ct) * 64)) | dbg_nostore), 0, 0);
-                    }
+                    for (int i = 0; i < R; ++i) b[(seq + 1) & 1][i] = *reinterpret_cast<const f32x4*>(lbase + next_off + i * ROW_OFF);
                 }
-            }
-        }
+                PCC_PIN_MEM_MFMA();
+                constexpr bool open = FIRST && T.first;  // first tap of the class in the first group: start from the bias
+                if constexpr (F16) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int ct = 0; ct < CTW; ++ct) acc[cls][i][ct] = mfma16h(wf[seq % RING][ct], b[seq & 1][i], open ? bias4[ct] : acc[cls][i][ct]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                            for (int ct = 0; ct < CTW; ++ct)
+                                acc[cls][i][ct] = mfma16(wf[seq % RING][ct][j], b[seq & 1][i][j], (open && j == 0) ? bias4[ct] : acc[cls][i][ct]);
+                }
+                if constexpr (LAST && T.last) {      // this class is complete: ReLU (/ residual / clip), stores (the bias is already in)
+                    constexpr int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+                    const unsigned coff = (unsigned)(((pz * a.OH + py) * a.OW + px) * a.ocs) * esz;  // (wave-uniform) bytes
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            f32x4 o = acc[cls][i][ct];
+                            // one v_maximum3_f32 per element (fmaxf on a raw MFMA result costs a second v_max that quiets NaNs)
+                            o = __builtin_elementwise_maximum(o, (f32x4){relu_lo, relu_lo, relu_lo, relu_lo});
+                            if constexpr (EPI == TR2G_EPI_ANY) {
+                                if (any_res) o += buf_load4(rres, roff_of(i), (unsigned)((((pz * a.OH + py) * a.OW + px) * COUT + (ct0 + ct) * 16) * 4));
+                                if (a.flags & PCC_CONV_CLIP01) {
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
+                                }
+                            }
+                            const unsigned boff = ooff[i] + coff + (unsigned)((ct0 + ct) * 16) * esz;
+                            if (EPI == TR2G_EPI_F16 || (EPI == TR2G_EPI_ANY && any_out16)) {
+                                h16x4 oh;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) oh[c] = (_Float16)o[c];
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oh), rout, (int)boff, 0, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)boff, 0, 0);
+                            }
+                        }
+                }
+            });
+        };
+        group(std::true_type{}, std::false_type{}, 0);
+#pragma unroll 1
+        for (int g = 1; g < C::NG - 1; ++g) group(std::false_type{}, std::false_type{}, g);
+        group(std::false_type{}, std::true_type{}, C::NG - 1);
 
         if (!has_next) break;
         tile = next; n = nn; bz0 = nbz0; by0 = nby0; bx0 = nbx0;
@@ -1464,43 +1495,38 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
         return launch(conv_tr2_kernel<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,     \
                       a.N * a.ntz * a.nty * a.ntx, a, st);                                              \
     }
+#define PCC_TR2G_EPI(TX, TZ, TY, TXT, R, CTW, F16, EPI)                                                  \
+    return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW, F16, EPI>, C::NT, C::LDS_BYTES,       \
+                  ntiles < slots ? ntiles : slots, a, st, ntiles);
 #define PCC_TR2G(TX, TZ, TY, TXT, R, CTW)                                                               \
-    {                                                                                                   \
+    if ((double)a.OD * a.OH * a.OW * a.ocs * 4.0 < 2147483648.0 && a.D < 512 && a.H < 512 && a.W < 512) { \
         using C = Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>;                                          \
         a.w += 27 * CIN * COUT;                                                                         \
         a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
         const int ntiles = a.N * a.ntz * a.nty * a.ntx;                                                 \
         const int slots = num_cu * (C::NT > 256 ? 1 : 2);                                               \
-        if (a.flags & PCC_CONV_F16)                                                                     \
-            return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW, true>, C::NT, C::LDS_BYTES,  \
-                          ntiles < slots ? ntiles : slots, a, st, ntiles);                              \
-        return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW>, C::NT, C::LDS_BYTES,        \
-                      ntiles < slots ? ntiles : slots, a, st, ntiles);                                  \
-    }
-#define PCC_TR2G3(TX, TZ, TY, TXT, R, CTW)                                                              \
-    {                                                                                                   \
-        using C = Tr2gCfg<CIN, COUT, TX, TZ, TY, TXT, R, CTW>;                                          \
-        a.w += 27 * CIN * COUT;                                                                         \
-        a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
-        const int ntiles = a.N * a.ntz * a.nty * a.ntx;                                                 \
-        const int slots = num_cu * 3;                                                                   \
-        return launch(conv_tr2g_kernel<CIN, COUT, TX, TZ, TY, TXT, R, CTW, false, 3>, C::NT, C::LDS_BYTES, \
-                      ntiles < slots ? ntiles : slots, a, st, ntiles);                                  \
+        const bool plain = !(a.flags & (PCC_CONV_ADD | PCC_CONV_CLIP01));                               \
+        if (a.flags & PCC_CONV_F16) {                                                                   \
+            if (plain && (a.flags & PCC_CONV_OUT16)) PCC_TR2G_EPI(TX, TZ, TY, TXT, R, CTW, true, TR2G_EPI_F16) \
+            if (plain) PCC_TR2G_EPI(TX, TZ, TY, TXT, R, CTW, true, TR2G_EPI_F32)                        \
+            PCC_TR2G_EPI(TX, TZ, TY, TXT, R, CTW, true, TR2G_EPI_ANY)                                   \
+        }                                                                                               \
+        if (plain) PCC_TR2G_EPI(TX, TZ, TY, TXT, R, CTW, false, TR2G_EPI_F32)                           \
+        PCC_TR2G_EPI(TX, TZ, TY, TXT, R, CTW, false, TR2G_EPI_ANY)                                      \
     }
     static const bool tr2_old = getenv("PCC_TR2_OLD") != nullptr;
     if (tx == 16) {
-        if constexpr (KS == 3) { if (!tr2_old) { static const int tv = getenv("PCC_TR2_VARIANT") ? atoi(getenv("PCC_TR2_VARIANT")) : 0;
-            if constexpr (CIN >= 64) { if (tv == 1) PCC_TR2G(16, 4, 4, 16, 2, 2) PCC_TR2G(16, 2, 4, 16, 2, 2) } else { if (tv == 1) PCC_TR2G(16, 4, 8, 16, 4, 1) if (tv == 2) PCC_TR2G(16, 2, 16, 16, 4, 1) if (tv == 3 && !(a.flags & PCC_CONV_F16)) PCC_TR2G3(16, 2, 4, 16, 2, 1) PCC_TR2G(16, 2, 8, 16, 4, 1) } } }
+        if constexpr (KS == 3) { if (!tr2_old) { if constexpr (CIN >= 64) { PCC_TR2G(16, 2, 4, 16, 2, 2) } else { PCC_TR2G(16, 2, 8, 16, 4, 1) } } }
         if constexpr (CIN >= 64) PCC_TR2(16, 2, 4, 16, 2)
         else PCC_TR2(16, 2, 8, 16, 4)
     }
     if (tx == 8) {
-        if constexpr (KS == 3) { if (!tr2_old) { if constexpr (COUT >= 64) PCC_TR2G(8, 2, 4, 8, 1, 1) else PCC_TR2G(8, 2, 8, 8, 2, 1) } }
+        if constexpr (KS == 3) { if (!tr2_old) { if constexpr (COUT >= 64) { PCC_TR2G(8, 2, 4, 8, 1, 1) } else { PCC_TR2G(8, 2, 8, 8, 2, 1) } } }
         if constexpr (COUT >= 64 && KS == 3) PCC_TR2C(8, 2, 4, 8, 1, 1)
         else PCC_TR2(8, 2, 8, 8, 2)
     }
 #undef PCC_TR2G
-#undef PCC_TR2G3
+#undef PCC_TR2G_EPI
     if constexpr (COUT >= 32 && KS == 3) PCC_TR2C(4, 1, 4, 4, 1, 1)
     else PCC_TR2(4, 4, 4, 4, 1)
 #undef PCC_TR2

@@ -91,10 +91,9 @@ PCC_API int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
     PCC_REQUIRE(!(d->flags & PCC_CONV_ADD) || residual, "pcc_conv3d: PCC_CONV_ADD set but residual is NULL");
     PCC_REQUIRE(d->out_cstride == 0 || d->out_cstride >= d->Cout + d->out_coffset,
                 "pcc_conv3d: out_cstride too small");
-    {   // bits 27..30 are profiling aids of conv_tr2g_kernel (skip stores / staging / weights): accepted only on request
-        static const bool prof = getenv("PCC_PROFILE_FLAGS") != nullptr;
+    {
         const int32_t known = PCC_CONV_BIAS | PCC_CONV_RELU | PCC_CONV_ADD | PCC_CONV_CLIP01 | PCC_CONV_F16 | PCC_CONV_IN16 | PCC_CONV_OUT16 | PCC_CONV_RES16;
-        PCC_REQUIRE((d->flags & ~(known | (prof ? 0x78000000 : 0))) == 0, "pcc_conv3d: unknown bits in flags");
+        PCC_REQUIRE((d->flags & ~known) == 0, "pcc_conv3d: unknown bits in flags");
     }
     PCC_REQUIRE(!(d->flags & (PCC_CONV_IN16 | PCC_CONV_OUT16 | PCC_CONV_RES16)) || (d->flags & PCC_CONV_F16),
                 "pcc_conv3d: fp16 storage (IN16 / OUT16 / RES16) exists only inside the fp16 mode (PCC_CONV_F16)");

@@ -201,7 +201,7 @@ def test_unknown_flag_bits_are_rejected(ctx):
     layer = ops.ConvLayer(np.zeros((3, 3, 3, 16, 16), np.float32), None, 1, False, False)
     x = torch.zeros((1, 4, 16, 16, 16), device=ctx.device)
     with pytest.raises(AssertionError):
-        ops.conv3d(ctx, x, layer, flags=0x40000000)      # a profiling bit without PCC_PROFILE_FLAGS
+        ops.conv3d(ctx, x, layer, flags=0x40000000)
     with pytest.raises(AssertionError):
         ops.conv3d(ctx, x, layer, flags=1 << 9)
 
