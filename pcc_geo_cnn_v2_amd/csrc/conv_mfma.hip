@@ -1216,7 +1216,9 @@ struct Cout1M {
     static constexpr int LYX = TYX + 2;                 // haloed plane edge
     static constexpr int NU = 336;                      // 21 N-tiles x 16 voxels >= 18*18 = 324
     static constexpr int NTILE = NU / 16;
-    static constexpr int LDS_BYTES = 27 * NU * 4;
+    static constexpr int RS = 340;                      // row pitch of P in floats: 4 * RS = 16 (mod 32) -> the four channel quads of a
+                                                        // ds_write_b32 fall on two bank halves (2 cycles, the minimum for 64 lanes) instead of one
+    static constexpr int LDS_BYTES = 32 * RS * 4;          // 32 tap rows: 27 + the zero rows of the second M tile
     static constexpr int PER_WAVE = (NTILE + 3) / 4;    // N-tiles per wave (6,5,5,5)
 };
 
@@ -1225,7 +1227,7 @@ struct Cout1M {
 template <bool IN16>
 __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
     using C = Cout1M;
-    extern __shared__ __attribute__((aligned(16))) float P[];   // [27][NU]
+    extern __shared__ __attribute__((aligned(16))) float P[];   // [32][RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v = lane & 15, cq = lane >> 4;
     int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -1316,14 +1318,15 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
                 d1[k] = mfma16(wA1[j], cur[k][j], j == 0 ? zero4 : d1[k]);
             }
         }
+        // all 32 tap rows are written (rows 27..31 are never read): no lane-dependent branch around the ds_writes
 #pragma unroll
         for (int k = 0; k < C::PER_WAVE; ++k) {
-            if (wave + 4 * k < C::NTILE) {
-                float* pw = P + uidx[k];
+            if (4 * k + 3 < C::NTILE || wave + 4 * k < C::NTILE) {      // (compile-time for all but the last, partial round of tiles)
+                float* pw = P + uidx[k] + 4 * cq * C::RS;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pw[(4 * cq + r) * C::NU] = d0[k][r];
-                    if (16 + 4 * cq + r < 27) pw[(16 + 4 * cq + r) * C::NU] = d1[k][r];
+                    pw[r * C::RS] = d0[k][r];
+                    pw[(16 + r) * C::RS] = d1[k][r];
                 }
             }
         }
@@ -1335,9 +1338,9 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const float* q = pcol + ky * C::LYX + kx;
-                s0 += q[(0 * 9 + ky * 3 + kx) * C::NU];
-                s1 += q[(1 * 9 + ky * 3 + kx) * C::NU];
-                s2 += q[(2 * 9 + ky * 3 + kx) * C::NU];
+                s0 += q[(0 * 9 + ky * 3 + kx) * C::RS];
+                s1 += q[(1 * 9 + ky * 3 + kx) * C::RS];
+                s2 += q[(2 * 9 + ky * 3 + kx) * C::RS];
             }
         accA += s0; accB += s1; accC += s2;
         if (p >= 1) finish(accC, p - 1);
