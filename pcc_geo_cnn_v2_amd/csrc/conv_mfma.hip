@@ -879,6 +879,13 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
     for (int ct = 0; ct < CTW; ++ct)
         bias4[ct] = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + (ct0 + ct) * 16 + cq * 4) : zero4;
 
+    // The weight stream wraps around: the last group of a tile prefetches the first RING - 1 taps of the NEXT tile (same
+    // weights).  Restarting it at the top of a tile would put those loads behind the tile's last stores, and the in-order
+    // vmcnt wait at the first barrier would then wait for the store acknowledgements.
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct0 + ct) * 1024u);
     f32x4 acc[8][R][CTW];
 #pragma unroll 1
     for (;;) {
@@ -886,11 +893,6 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
         const bool has_next = next < ntiles;
         int nn = n, nbz0 = bz0, nby0 = by0, nbx0 = bx0;
         if (has_next) decode(next, nn, nbz0, nby0, nbx0);
-        // the weight stream restarts per tile
-#pragma unroll
-        for (int r = 0; r < RING - 1; ++r)
-#pragma unroll
-            for (int ct = 0; ct < CTW; ++ct) wf[r][ct] = buf_load4(rw, wlane, (unsigned)(r * C::NCT + ct0 + ct) * 1024u);
         // per-row output BYTE offsets of this tile for class (0,0,0) (the epilogue of a parity class runs inside the last
         // group, right after the class's taps: the 8 x R x CTW stores of a tile are spread over that group instead of bursting
         // at its end).  One descriptor per tile (image n); the class adds a wave-uniform offset.  kOOB plus those offsets
@@ -935,10 +937,11 @@ conv_tr2g_kernel(ConvArgs a, int ntiles) {
                 constexpr Tr2gTap Tn = tr2g_tap(seq + 1 < NSEQ ? seq + 1 : seq);
                 constexpr int next_off = ((Tn.dz * C::LY + Tn.dy) * C::LX + Tn.dx) * C::VS;
                 constexpr int cls = T.cls;
-                // weights RING - 1 taps ahead (runs into the next group's first taps; past the end: zeros)
+                // weights RING - 1 taps ahead: runs into the next group's first taps, and from the last group into the next tile's
+                constexpr bool wrap = LAST && seq + RING - 1 >= NSEQ;
 #pragma unroll
                 for (int ct = 0; ct < CTW; ++ct)
-                    wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, wg_off + (unsigned)((seq + RING - 1) * C::NCT + ct0 + ct) * 1024u);
+                    wf[(seq + RING - 1) % RING][ct] = buf_load4(rw, wlane, (wrap ? 0u : wg_off) + (unsigned)((seq + RING - 1 - (wrap ? NSEQ : 0)) * C::NCT + ct0 + ct) * 1024u);
                 if constexpr (seq + 1 < NSEQ) {
 #pragma unroll
                     for (int i = 0; i < R; ++i) b[(seq + 1) & 1][i] = *reinterpret_cast<const f32x4*>(lbase + next_off + i * ROW_OFF);
