@@ -63,8 +63,10 @@ int pcc_ctx_num_cu(pcc_ctx* ctx);
 /* fp16 STORAGE inside the fp16 mode (mid-network tensors of the c3 / c3p blocks; used by pcc_network_forward with
  * PCC_CONV_F16, accepted here for callers that chain layers themselves).  Buffers are passed through the same pointers.   */
 #define PCC_CONV_IN16 32   /* `in` (and `residual`, if any: see RES16) are fp16 NDHWC: k3 stride-1 layers with Cin = Cout in
-                              {16, 32} and H, W multiples of 16 (conv_f16.hip, v_mfma_f32_16x16x32_f16), and the 16 -> 1
-                              k3 stride-1 transposed layer                                                                */
+                              {16, 32, 64} and H, W multiples of 16 (conv_f16.hip, v_mfma_f32_16x16x32_f16), and the 16 -> 1
+                              k3 stride-1 transposed layer.  The 64-channel layers keep fp16 partial sums of the first input
+                              half in a scratch tensor owned by the context (allocated on first use, N*D*H*W*128 bytes):
+                              calls that use it must be ordered on one stream per context                                 */
 #define PCC_CONV_OUT16 64  /* `out` is fp16 NDHWC: the IN16 layers and the k3 stride-2 transposed layers                  */
 #define PCC_CONV_RES16 128 /* `residual` is fp16 (always together with IN16)                                              */
 
