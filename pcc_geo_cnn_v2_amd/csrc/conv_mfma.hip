@@ -85,7 +85,13 @@ __device__ __forceinline__ void store_out(const ConvArgs& a, f32x4 v, size_t vox
         v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
         v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
     }
-    *reinterpret_cast<f32x4*>(a.out + vox * a.ocs + a.oco + c0) = v;
+    if (a.flags & PCC_CONV_OUT16) {      // fp16 hand-over to conv_f16.hip (fp16 mode): 8 bytes per lane
+        h16x4 h;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.out) + vox * a.ocs + a.oco + c0) = h;
+    } else {
+        *reinterpret_cast<f32x4*>(a.out + vox * a.ocs + a.oco + c0) = v;
+    }
 }
 
 // XCD-aware tile index: consecutive tile ids go to the same XCD (blocks are dispatched round-robin over
@@ -278,7 +284,13 @@ conv_fwd_kernel(ConvArgs a) {
                         o.x = fminf(fmaxf(o.x, 0.f), 1.f); o.y = fminf(fmaxf(o.y, 0.f), 1.f);
                         o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
                     }
-                    *reinterpret_cast<f32x4*>(a.out + vox * a.ocs + a.oco + c0) = o;
+                    if (a.flags & PCC_CONV_OUT16) {      // (wave-uniform) fp16 hand-over, as store_out
+                        h16x4 h;
+                        h[0] = (_Float16)o.x; h[1] = (_Float16)o.y; h[2] = (_Float16)o.z; h[3] = (_Float16)o.w;
+                        *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.out) + vox * a.ocs + a.oco + c0) = h;
+                    } else {
+                        *reinterpret_cast<f32x4*>(a.out + vox * a.ocs + a.oco + c0) = o;
+                    }
                 }
             }
         }
@@ -1493,7 +1505,6 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
 #define PCC_TR2C(TX, TZ, TY, TXT, R, CTW)                                                               \
     {                                                                                                   \
         using C = Tr2Cfg<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW>;                                       \
-        if (a.flags & PCC_CONV_OUT16) { pcc_set_error("pcc_conv3d: PCC_CONV_OUT16 needs the k3 group-pipelined transposed kernel (input W multiple of 8)"); return PCC_ERR_ARG; } \
         a.ntz = cdiv(a.D, TZ); a.nty = cdiv(a.H, TY); a.ntx = cdiv(a.W, TXT);                           \
         if (a.flags & PCC_CONV_F16)                                                                     \
             return launch(conv_tr2_kernel<CIN, COUT, KS, TX, TZ, TY, TXT, R, CTW, true>, C::NT, C::LDS_BYTES, \
@@ -1719,6 +1730,8 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 
 #define PCC_CASE_FWD(CI, CO, K, S) if (ci == CI && co == CO && k == K && fs == S) return launch_fwd<CI, CO, K, S>(p.tx, a, st, ctx->num_cu);
 #define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st, ctx->num_cu);
+    PCC_REQUIRE(!(d->flags & PCC_CONV_OUT16) || p.kind == K_FWD || p.kind == K_TR2 || p.kind == K_CIN1,
+                "pcc_conv3d: PCC_CONV_OUT16 needs a layer with Cout a multiple of 16");
     if ((d->flags & (PCC_CONV_IN16 | PCC_CONV_RES16)) && p.kind != K_COUT1M) {
         // fp16-storage layer (conv_f16.hip): fp16 input (and residual), fp16 or fp32 output
         PCC_REQUIRE(p.kind == K_FWD && (d->flags & PCC_CONV_IN16) && pcc_f16_eligible(d),
@@ -1727,7 +1740,7 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
         return pcc_conv_f16(ctx, d, in, f16w, bias, residual, out, !(d->flags & PCC_CONV_OUT16), st);
     }
     if (p.kind == K_FWD) {
-        PCC_REQUIRE(!(d->flags & PCC_CONV_OUT16), "pcc_conv3d: PCC_CONV_OUT16 is implemented by the k3 stride-2 transposed kernel and the fp16 layers");
+        PCC_REQUIRE(!(d->flags & PCC_CONV_OUT16) || d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_CONV_OUT16 is not implemented by the Winograd kernel (fp32)");
         const int fs = p.flip ? 1 : s;
         if (pcc_wino_channels(ci, co) && k == 3 && fs == 1) {
             static const bool no_wino = getenv("PCC_NO_WINOGRAD") != nullptr;

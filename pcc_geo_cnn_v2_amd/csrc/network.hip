@@ -255,19 +255,21 @@ PCC_API int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters
     const float* t1 = nullptr;
     int cur = 0;                 // rotating buffer that receives the next output
     int in_buf = -1, t1_buf = -1;
-    // fp16 mode: inside a SynthesisBlock (width 16, 32 or 64) the two intermediate tensors (tensor1 and the output of the
-    // middle conv) live in HBM as fp16: the stride-2 transposed conv hands over in fp16 (PCC_CONV_OUT16), the two k3 stride-1
-    // convs run on conv_f16.hip (PCC_CONV_IN16), the last one adds the fp16 residual and writes fp32 for the next block.
+    // fp16 mode: inside an AnalysisBlock / SynthesisBlock (width 16, 32 or 64) the two intermediate tensors (tensor1 and the
+    // output of the middle conv) live in HBM as fp16: the stride-2 (transposed) conv hands over in fp16 (PCC_CONV_OUT16), the two k3
+    // stride-1 convs run on conv_f16.hip (PCC_CONV_IN16), the last one adds the fp16 residual and writes fp32 for the next block.
     int f16_block_left = 0;      // layers of the current fp16-storage block still to come
     bool final_in16 = false;
     for (size_t i = 0; i < v.size(); ++i) {
         const LayerSpec& L = v[i];
         const bool last = i + 1 == v.size();
         int storage = 0;
-        if ((layer_flags & PCC_CONV_F16) && L.res == 1 && L.transposed && L.stride == 2 && L.k == 3 && (L.cout == 16 || L.cout == 32 || L.cout == 64) &&
-            (2 * H) % 16 == 0 && (2 * W) % 16 == 0 && W % 8 == 0 && i + 2 < v.size() && v[i + 1].res == 0 && v[i + 2].res == 2 &&
-            v[i + 1].k == 3 && v[i + 1].stride == 1 && v[i + 2].k == 3 && v[i + 2].stride == 1) {
-            storage = PCC_CONV_OUT16;
+        const int oH = L.transposed ? 2 * H : H / 2, oW = L.transposed ? 2 * W : W / 2;      // (stride-2 layers)
+        if ((layer_flags & PCC_CONV_F16) && L.res == 1 && L.stride == 2 && L.k == 3 && (L.cout == 16 || L.cout == 32 || L.cout == 64) &&
+            oH % 16 == 0 && oW % 16 == 0 && H % 2 == 0 && W % 2 == 0 && i + 2 < v.size() && v[i + 1].res == 0 && v[i + 2].res == 2 &&
+            v[i + 1].k == 3 && v[i + 1].stride == 1 && v[i + 2].k == 3 && v[i + 2].stride == 1 &&
+            [&] { const pcc_conv_desc d0 = layer_desc(L, im[i].cin, N, D, H, W, layer_flags); return pcc_conv_mfma_supported(&d0) == 1; }()) {
+            storage = PCC_CONV_OUT16;       // (a layer on the generic path cannot hand over in fp16)
             f16_block_left = 2;
         } else if (f16_block_left == 2) {
             storage = PCC_CONV_IN16 | PCC_CONV_OUT16;

@@ -258,6 +258,21 @@ def test_fp16_storage_conv_matches_oracle(ctx, case):
     assert (g - ref).abs().max().item() <= TOL_F16 * scale
 
 
+@pytest.mark.parametrize('cin,cout,tr,D', [(1, 16, False, 32), (1, 32, False, 32), (16, 32, False, 32), (32, 64, False, 16), (64, 64, False, 8),
+                                           (32, 16, True, 16), (64, 32, True, 8), (64, 64, True, 4), (32, 32, True, 4)])
+def test_fp16_handover_of_the_stride2_layers(ctx, cin, cout, tr, D):
+    """PCC_CONV_OUT16 on the first (stride-2) layer of an AnalysisBlock / SynthesisBlock (/root/reference/src/model_transforms.py:
+    62-81): the fp16 tensor is the fp16 rounding of what the same kernel stores in fp32."""
+    rng = np.random.default_rng(cin + cout)
+    w = (rng.standard_normal((3, 3, 3, cout, cin) if tr else (3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    layer = ops.ConvLayer(w, rng.standard_normal(cout).astype(np.float32), 2, tr, True)
+    x = torch.randn((2, D, D, D, cin), generator=torch.Generator().manual_seed(D)).to(ctx.device)
+    ref = ops.conv3d(ctx, x, layer, flags=L.PCC_CONV_F16)
+    got = ops.conv3d_fp16_storage(ctx, x, layer, None, in16=False, out16=True)
+    torch.cuda.synchronize()
+    assert got.dtype == torch.float16 and torch.equal(got, ref.half())
+
+
 def test_fp16_storage_flags_are_checked(ctx):
     rng = np.random.default_rng(0)
     layer = ops.ConvLayer((rng.standard_normal((3, 3, 3, 16, 16)) / 20).astype(np.float32), None, 1, False, False)
