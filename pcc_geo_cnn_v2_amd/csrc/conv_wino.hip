@@ -309,10 +309,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
                 for (int q = 2 * (j - 8); q < 2 * (j - 8) + 2; ++q) {
                     f32x4 o = S[q >> 1][q & 1];
                     if (PRE) o = add4(o, prev[q]);
-                    if (RELU) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
-                    }
+                    // one v_maximum3_f32 per element: fmaxf on the result of the inline-asm packed add costs a second v_max (NaN quieting)
+                    if (RELU) o = __builtin_elementwise_maximum(o, (f32x4){0.f, 0.f, 0.f, 0.f});
                     o = add4(o, resv[q]);     // zeros without PCC_CONV_ADD (zero-sized buffer)
                     if (CLIP) {
 #pragma unroll
