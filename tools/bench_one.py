@@ -12,8 +12,6 @@ layer = ops.ConvLayer((rng.standard_normal(wshape) / np.sqrt(k ** 3 * cin)).asty
 x = torch.randn((B, D, D, D, cin), device=ctx.device)
 res = torch.randn(ops.conv_out_shape(layer, x.shape), device=ctx.device) if len(sys.argv) > 8 else None
 FL = int(os.environ.get('PCC_BENCH_FLAGS', '0'), 0)
-if FL & ~31:
-    os.environ['PCC_PROFILE_FLAGS'] = '1'      # the library rejects unknown flag bits unless asked
 out = ops.conv3d(ctx, x, layer, residual=res, impl=IMPL, flags=FL)
 torch.cuda.synchronize()
 ts = []
