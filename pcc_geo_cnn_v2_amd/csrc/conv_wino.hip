@@ -61,6 +61,7 @@ constexpr int PLANE_BYTES = CHUNKS * 1024;             // 21504: three planes en
 constexpr int U_BASE = 3 * PLANE_BYTES;
 constexpr int U_BYTES = 48 * 1024;                     // 3 z taps x 16 points x 64 lanes x float4
 constexpr int LDS_BYTES = U_BASE + U_BYTES;            // 113664
+constexpr int LDS_BYTES_MULTI = U_BASE + 2 * U_BYTES;  // 162816 <= 160 KB: U double-buffered across the cin groups of one launch
 constexpr int ITEMS = 6;                               // chunks per wave: wave w stages chunks 5w .. 5w+5 (5, 10, 15 twice: same data)
 
 struct WinoArgs {
@@ -75,6 +76,7 @@ struct WinoArgs {
     int flags, ocs, oco;
     int ics, ico;       // input channel stride / offset of this launch's 16-channel cin group
     int rcs;            // residual channel stride (its channel offset follows the cout group)
+    int ncig;           // MULTI: cin groups processed by one launch (u: [cin group][cout group][48][64][4])
 };
 
 // Measured on MI355X (tools/ubench/mfma_valu.hip): a wave's VALU instructions do NOT overlap with its own fp32 MFMAs
@@ -124,8 +126,16 @@ __device__ __forceinline__ void transform_y_row(f32x4 (&V)[16], const f32x4 (&P)
     }
 }
 
-template <bool RELU, bool CLIP, bool PRE>
+// MULTI: all cin groups of a Cin = Cout = 16 g layer in ONE launch.  A workgroup marches over its z slab once per cin group,
+// one after the other, as one continuous sequence of steps: the plane ring, the accumulator rotation and the U prefetch run
+// across the group boundary (the last two steps of a group prefetch the first two planes of the next one; the next group's U
+// arrives global -> LDS into the second U buffer during the march), the partial sums of the earlier groups are read back from
+// `out` (same lane, same address as its own earlier store), bias / ReLU / residual are applied in the last group only.  Same
+// arithmetic and summation order as one launch per group (PRE), without the launch boundaries, the per-launch U load and
+// the pipeline refill.
+template <bool RELU, bool CLIP, bool PRE, bool MULTI = false>
 __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg) {
+    static_assert(!MULTI || (!PRE && !CLIP), "MULTI covers the whole layer; clip layers take the per-group launches");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = lane & 15, g = lane >> 4;
@@ -190,7 +200,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             const int v = 36 * TY + 18 * dy + 9 * (dx & 1) + TX + (dx >> 1);
             ra[dy * 4 + dx] = (unsigned)(v * 64 + ((g ^ ((v >> 1) & 3)) << 4));
         }
-    const unsigned ua = (unsigned)(U_BASE + lane * 16);
+    unsigned ua = (unsigned)(U_BASE + lane * 16);          // (MULTI: toggles between the two U buffers per cin group)
 
     // ---- epilogue addressing: lane writes couts 4g..4g+3 of the 2x2 voxels of its tile
     const int ox0 = X0 + 2 * TX, oy0 = Y0 + 2 * TY;
@@ -206,7 +216,13 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     const float* res_n = has_res ? a.res + (size_t)n * a.D * HW * a.rcs : a.in;
     float* out_n = a.out + (size_t)n * a.D * HW * a.ocs;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 bias4 = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + 16 * cog + g * 4) : zero4;
+    const f32x4 bias_l = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + 16 * cog + g * 4) : zero4;
+    // MULTI: per-group state (wave-uniform).  The bias enters in the LAST group, like in the per-group launches.
+    int cig = 0, sl = 0;                                   // current cin group, step inside its march
+    bool fin = !MULTI || a.ncig == 1;
+    f32x4 bias4 = fin ? bias_l : zero4;
+    const f32x4 ninf4 = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    f32x4 relu4 = fin ? zero4 : ninf4;                     // lower clamp of the epilogue: 0 in the last group of a ReLU layer
 
     // ---- prologue: input planes s = 0, 1 (z = zb-1, zb) -> ring slots 0, 1
     stage_plane(0, zb - 1);
@@ -233,16 +249,22 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;     // plane zo of step s = 0
     unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
     // one input plane: s = step index (input plane z = zb-1+s), PH = s mod 3
-    auto step = [&](auto ph_tag, int s) __attribute__((always_inline)) {
+    auto step = [&](auto ph_tag, int s_arg) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
+        const int s = MULTI ? sl : s_arg;
         constexpr unsigned slotN = (unsigned)((PH + 1) % 3) * PLANE_BYTES;   // plane s+1 (read)
         constexpr unsigned slotW = (unsigned)((PH + 2) % 3) * PLANE_BYTES;   // plane s+2 (written)
         constexpr int AF = PH;                                               // acc slot of the plane finished by dz = 2
         const bool zo_ok = s >= 2;                                           // the finished plane zo = zb - 2 + s exists
         // plane-sized descriptors of the finished output plane; zero-sized (loads return 0, stores are dropped) while s < 2
-        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res ? HWR : 0u);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res && fin ? HWR : 0u);
+        // MULTI: the partial sums of the earlier groups (zero-sized for the first group: loads return 0)
+        const __amdgpu_buffer_rsrc_t rpre = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), MULTI && zo_ok && cig > 0 ? HWO : 0u);
         const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok ? HWO : 0u);
         res_pl += HWR; out_pl += HWO;
+        const bool last_of_group = MULTI && s == nsteps - 1;
+        constexpr unsigned UTOG = (unsigned)(U_BASE ^ (U_BASE + U_BYTES));      // the two U bases differ in bits above lane * 16
+        const unsigned ua_next = last_of_group ? (ua ^ UTOG) : ua;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int dz = 2 - (j >> 2), py = j & 3;
@@ -251,7 +273,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             {
                 const int jn = (j + 1) % 12, dzn = 2 - (jn >> 2), pyn = jn & 3;
 #pragma unroll
-                for (int px = 0; px < 4; ++px) Ub[(j + 1) & 1][px] = ldsr(ua + (unsigned)(((dzn * 4 + pyn) * 4 + px) * 1024));
+                for (int px = 0; px < 4; ++px) Ub[(j + 1) & 1][px] = ldsr((j == 11 ? ua_next : ua) + (unsigned)(((dzn * 4 + pyn) * 4 + px) * 1024));
             }
             // (2) the 16 MFMAs of this row: 4 independent accumulators, k-chained; dz = 0 opens a new output plane
 #pragma unroll
@@ -271,10 +293,20 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             //     the next plane are written in slots 9, 10, 11 and (row 3) slot 0 of the next step: no register copies.
             if (j == 0) transform_y_row(Vc, Vn, 3);
             else if (j == 1) {
-                {
+                if constexpr (!MULTI) {
                     const bool ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
                     const __amdgpu_buffer_rsrc_t rp = make_rsrc((const void*)(ok ? in_pl : (unsigned long long)in_n), ok ? HWI : 0u);
                     in_pl += HWI;
+#pragma unroll
+                    for (int it = 0; it < ITEMS; ++it)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + slotW + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
+                } else {
+                    // plane two steps ahead in the continuous sequence: inside this group, or plane 0 / 1 of the next group
+                    const bool wrap = s + 2 >= nsteps;
+                    const int zl = wrap ? s + 2 - nsteps : s + 2;              // step index inside its group
+                    const int z = zb - 1 + zl, cg = wrap ? cig + 1 : cig;
+                    const bool ok = (unsigned)z < (unsigned)a.D && cg < a.ncig;
+                    const __amdgpu_buffer_rsrc_t rp = make_rsrc(ok ? in_n + (size_t)z * HW * a.ics + 16 * cg : in_n, ok ? HWI - (unsigned)(64 * cg) : 0u);
 #pragma unroll
                     for (int it = 0; it < ITEMS; ++it)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + slotW + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
@@ -285,11 +317,13 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             else if (j == 3) transform_x_rows(Vn, 2, 4);
             else if (j == 4 || j == 5) {
                 // residual (and partial sums of the previous cin groups, accumulated in place in `out`: same lane, same
-                // address) of the two voxels of output row oy = j - 4
+                // address) of the two voxels of output row oy = j - 4.  (Requesting them in slot 0 instead was measured: no
+                // change for the one-group layers, 8 % more cycles for the two-group ones.)
 #pragma unroll
                 for (int q = 2 * (j - 4); q < 2 * (j - 4) + 2; ++q) {
                     resv[q] = buf_load4(rres, rvo[q], 0);
                     if (PRE) prev[q] = buf_load4(rout, ovo[q], 0);
+                    if (MULTI) prev[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpre, (int)ovo[q], 0, 1));   // glc: this lane's own earlier store, past the L1
                 }
             }
             if (j >= 5 && j <= 8) {
@@ -308,9 +342,9 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
                 for (int q = 2 * (j - 8); q < 2 * (j - 8) + 2; ++q) {
                     f32x4 o = S[q >> 1][q & 1];
-                    if (PRE) o = add4(o, prev[q]);
+                    if (PRE || MULTI) o = add4(o, prev[q]);
                     // one v_maximum3_f32 per element: fmaxf on the result of the inline-asm packed add costs a second v_max (NaN quieting)
-                    if (RELU) o = __builtin_elementwise_maximum(o, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    if (RELU) o = __builtin_elementwise_maximum(o, MULTI ? relu4 : zero4);
                     o = add4(o, resv[q]);     // zeros without PCC_CONV_ADD (zero-sized buffer)
                     if (CLIP) {
 #pragma unroll
@@ -332,19 +366,43 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             if (j == 9) transform_y_row(Vc, Vn, 0);
             else if (j == 10) transform_y_row(Vc, Vn, 1);
             else if (j == 11) transform_y_row(Vc, Vn, 2);
+            if (MULTI && (j == 10 || j == 11)) {
+                // U of the next group -> the other U buffer, 48 chunks of 1 KB: 12 per wave, one in each of these two VALU-light
+                // slots over the first six steps of the march (they are older than the last 12 memory ops of the NEXT step, whose
+                // closing vmcnt wait therefore covers them: complete by the end of step 6 <= nsteps - 2)
+                if (s < 6 && cig + 1 < a.ncig) {
+                    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u + ((size_t)(cig + 1) * a.nco + cog) * (U_BYTES / 4), (unsigned)U_BYTES);
+                    const unsigned ub = (ua ^ UTOG) - (unsigned)(lane * 16);       // base of the other buffer
+                    const int chunk = wave * 12 + 2 * s + (j - 10);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr)(smem + ub + chunk * 1024), 16, (int)(lane * 16), chunk * 1024, 0, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // The LDS-direct loads of plane s+2 (slot 1) must have landed before the barrier publishes them to the other
         // waves; the compiler only orders them against this wave's own LDS reads.  vmcnt counts in issue order: the 4
-        // residual (+4 partial-sum) loads of slot 4 and the 4 stores of slot 9 issued later may stay in flight.
-        __builtin_amdgcn_s_waitcnt(PRE ? 0x0F7C : 0x0F78);      // vmcnt(8 or 12) expcnt(7) lgkmcnt(15)
+        // residual (+4 partial-sum) loads of slots 4 / 5, the 4 stores of slots 8 / 9 (and MULTI's two U pieces of slots
+        // 10 / 11) were issued later and may stay in flight.
+        __builtin_amdgcn_s_waitcnt(MULTI ? 0x0F7E : PRE ? 0x0F7C : 0x0F78);      // vmcnt(14 / 12 / 8) expcnt(7) lgkmcnt(15)
         __syncthreads();     // plane s+2 is published; nobody still reads plane s+1
+        if constexpr (MULTI) {
+            if (++sl == nsteps) {       // (wave-uniform) next cin group: same slab, same outputs
+                sl = 0; ++cig;
+                fin = cig == a.ncig - 1;
+                bias4 = fin ? bias_l : zero4;
+                relu4 = fin ? zero4 : ninf4;
+                ua ^= UTOG;
+                res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;
+                out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
+            }
+        }
     };
 
-    for (int s = 0; s < nsteps; s += 3) {
+    const int total = MULTI ? nsteps * a.ncig : nsteps;
+    for (int s = 0; s < total; s += 3) {
         step(std::integral_constant<int, 0>{}, s);
-        if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
-        if (s + 2 < nsteps) step(std::integral_constant<int, 2>{}, s + 2);
+        if (s + 1 < total) step(std::integral_constant<int, 1>{}, s + 1);
+        if (s + 2 < total) step(std::integral_constant<int, 2>{}, s + 2);
     }
 }
 
@@ -393,6 +451,24 @@ int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const f
             PCC_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         configured = true;
     }
+    // all cin groups of a 64-channel layer in one launch (MULTI) unless the layer clips, its slabs are too short for the U
+    // prefetch schedule, or PCC_WINO_PER_GROUP asks for the per-group launches (bit-identical results: tests compare the two).
+    // Measured: 64 -> 64 @16^3 x32 173 -> 167 us (launch boundaries); 32 -> 32 @32^3 (two groups) gains nothing and stays per group.
+    const bool per_group = getenv("PCC_WINO_PER_GROUP") != nullptr;       // (read per call: a test flips it)
+    if (G >= 4 && !(d->flags & PCC_CONV_CLIP01) && a.zlen >= 6 && !per_group) {
+        static const kern_t mk[2] = {conv16_wino_kernel<false, false, false, true>, conv16_wino_kernel<true, false, false, true>};
+        static thread_local bool mconf = false;
+        if (!mconf) {
+            for (int i = 0; i < 2; ++i)
+                PCC_CHECK_HIP(hipFuncSetAttribute((const void*)mk[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_MULTI));
+            mconf = true;
+        }
+        a.u = u_packed; a.ico = 0; a.ncig = G; a.flags = d->flags;
+        hipLaunchKernelGGL(mk[(d->flags & PCC_CONV_RELU) ? 1 : 0], dim3((unsigned)nwg), dim3(NT), LDS_BYTES_MULTI, st, a, nwg);
+        PCC_CHECK_HIP(hipGetLastError());
+        return PCC_OK;
+    }
+    a.ncig = 1;
     for (int ci = 0; ci < G; ++ci) {
         const bool last = ci == G - 1;
         a.u = u_packed + (size_t)ci * G * (U_BYTES / 4);

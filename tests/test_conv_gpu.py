@@ -219,6 +219,29 @@ def test_concat_mode_channel_offset(ctx, oracle):
     assert np.all(got[..., :4] == 0) and np.all(got[..., 7] == 0)
 
 
+@pytest.mark.parametrize('C,N,D,H,W,tr,res,relu', [(32, 3, 32, 32, 32, True, True, True), (64, 5, 16, 16, 16, True, True, True), (64, 2, 16, 32, 16, False, False, False),
+                                                     (32, 1, 6, 16, 48, False, True, True), (64, 1, 7, 16, 16, True, True, True), (32, 2, 64, 16, 16, True, False, True),
+                                                     (64, 32, 16, 16, 16, True, True, True)])
+def test_winograd_all_cin_groups_in_one_launch_is_bit_identical_to_per_group_launches(ctx, monkeypatch, C, N, D, H, W, tr, res, relu):
+    """conv16_wino_kernel<MULTI>: the cin groups of a 32- / 64-channel k3 stride-1 layer (/root/reference/src/model_transforms.py:
+    62-81) marched one after the other inside ONE launch == one launch per group (PCC_WINO_PER_GROUP), bit for bit, and both
+    within the Winograd tolerance of the direct kernel."""
+    rng = np.random.default_rng(C + D)
+    w = (rng.standard_normal((3, 3, 3, C, C)) / np.sqrt(27 * C)).astype(np.float32)
+    layer = ops.ConvLayer(w, rng.standard_normal(C).astype(np.float32), 1, tr, relu)
+    x = torch.randn((N, D, H, W, C), generator=torch.Generator().manual_seed(D)).to(ctx.device)
+    r = torch.randn((N, D, H, W, C), generator=torch.Generator().manual_seed(D + 1)).to(ctx.device) if res else None
+    a = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_WINOGRAD)
+    a2 = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_WINOGRAD)
+    monkeypatch.setenv('PCC_WINO_PER_GROUP', '1')
+    b = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_WINOGRAD)
+    monkeypatch.delenv('PCC_WINO_PER_GROUP')
+    d = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_MFMA)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a2) and torch.equal(a, b)
+    assert (a - d).abs().max().item() <= 2e-5 * (1 + d.abs().max().item())
+
+
 F16S_CASES = [  # C, N, D, H, W, transposed, residual, out16
     (16, 2, 5, 16, 16, True, False, True), (16, 1, 9, 32, 48, False, True, True), (16, 2, 6, 16, 32, True, True, False),
     (32, 1, 5, 16, 16, True, False, True), (32, 2, 7, 32, 16, False, True, False), (16, 3, 32, 32, 32, True, True, True),
