@@ -25,4 +25,4 @@ for rep in range(5):
 ms = min(ts)
 od = D * s if tr else D // s
 macs = B * (D ** 3 if tr else od ** 3) * k ** 3 * cin * cout
-print(f"impl={IMPL} " B={B} D={D} {cin}->{cout} k{k} s{s} tr{tr}: min {ms*1000:.1f} us median {sorted(ts)[2]*1000:.1f} us  {2*macs/ms/1e9:.1f} TFLOP/s ({100*2*macs/ms/1e9/157.3:.1f}%)')
+print(f'impl={IMPL} B={B} D={D} {cin}->{cout} k{k} s{s} tr{tr}: min {ms*1000:.1f} us median {sorted(ts)[2]*1000:.1f} us  {2*macs/ms/1e9:.1f} TFLOP/s ({100*2*macs/ms/1e9/157.3:.1f}%)')
