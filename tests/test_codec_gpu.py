@@ -50,7 +50,8 @@ def scaled_weights(model, gain):
 CF, CL = 'channels_first', 'channels_last'
 BLOCK_CASES = [('c1', 32, 'c', CF), ('c2', 32, 'c', CF), ('c3', 32, 'c', CF), ('c3p', 32, 'c', CF), ('c3p', 16, 'c', CF),
                ('c1', 32, 'c', CL), ('c3p', 32, 'c', CL),
-               ('c1', 64, 'torch', CF), ('c3p', 64, 'torch', CF), ('c2', 64, 'torch', CF)]
+               ('c1', 64, 'torch', CF), ('c3p', 64, 'torch', CF), ('c2', 64, 'torch', CF), ('c3', 64, 'torch', CF), ('c3p', 64, 'torch', CL),
+               ('c3p', 128, 'torch', CF)]
 
 
 @pytest.mark.parametrize('name,res,backend,data_format', BLOCK_CASES)
