@@ -138,7 +138,8 @@ int pcc_network_out_dims(int32_t transform, int32_t filters, int32_t D, int32_t 
                          int32_t* OW, int32_t* OC);
 /* y = transform(x).  x: (N,D,H,W,Cin) with Cin = 1 for the analysis transforms, `filters` otherwise; y: NDHWC of
  * pcc_network_out_dims.  layer_flags: 0 or PCC_CONV_F16 (every layer); final_flags: 0 or PCC_CONV_CLIP01 (last layer).
- * Results are bit-identical to the same layers issued one by one through pcc_conv3d.                                      */
+ * Results are bit-identical to the same layers issued one by one through pcc_conv3d (with layer_flags = PCC_CONV_F16 the
+ * library additionally keeps the mid-block tensors of the residual blocks in fp16: PCC_CONV_IN16 / OUT16 / RES16 above).  */
 int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x, int32_t N,
                         int32_t D, int32_t H, int32_t W, float* y, void* workspace, size_t workspace_bytes,
                         int32_t layer_flags, int32_t final_flags, void* stream);
