@@ -157,6 +157,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--chunk', type=int, default=CHUNK)
+    ap.add_argument('--coder-threads', type=int, default=0,
+                    help='host range-coder threads of this rank (default: logical cores / ranks); for studying the host share')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
                     help="fp32 = the reference's arithmetic (the headline number); fp16 = fp16 MFMA / fp32 accumulate (BASELINE.json configs[4] flavour, informational)")
     ap.add_argument('--workload', default='configs1', choices=['configs1', 'configs4'],
@@ -195,7 +197,7 @@ def main():
     ctx = ops.get_context(device)
 
     # host range-coder threads: share the node's cores between the ranks
-    coder_threads = max(8, (os.cpu_count() or 8) // max(world, 1))
+    coder_threads = args.coder_threads or max(8, (os.cpu_count() or 8) // max(world, 1))
     model = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads, precision=args.precision)
     model.compress([1, 1, RES, RES, RES])
     w = synthetic_weights(model)
