@@ -65,4 +65,20 @@ void pcc_f16_pack(int C, const float* wlog, unsigned short* out);
 int pcc_conv_f16(pcc_ctx* ctx, const pcc_conv_desc* d, const void* in, const void* w_packed, const float* bias,
                  const void* residual, void* out, bool out32, hipStream_t st);
 constexpr int PCC_WINO_U_FLOATS = 48 * 64 * 4;   // per (cin group, cout group): [z tap][point][lane][cin quad member]
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is set per DEVICE:
+// remember the (function, device) pairs this thread has configured.
+#include <utility>
+#include <vector>
+inline int pcc_enable_big_lds(const void* kern, int lds_bytes) {
+    if (lds_bytes <= 64 * 1024) return PCC_OK;
+    static thread_local std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    PCC_CHECK_HIP(hipGetDevice(&dev));
+    for (const auto& e : done)
+        if (e.first == kern && e.second == dev) return PCC_OK;
+    PCC_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    done.emplace_back(kern, dev);
+    return PCC_OK;
+}
+
 inline bool pcc_wino_channels(int cin, int cout) { return cin == cout && (cin == 16 || cin == 32 || cin == 64); }

@@ -354,11 +354,7 @@ int pcc_conv_f16(pcc_ctx* ctx, const pcc_conv_desc* d, const void* in, const voi
     const int nwg = base * zs;
 #define PCC_F16_LAUNCH(CC, O32, SUB)                                                                                  \
     {                                                                                                                 \
-        static thread_local bool conf = false;                                                                        \
-        if (!conf) {                                                                                                  \
-            PCC_CHECK_HIP(hipFuncSetAttribute((const void*)conv_f16_kernel<CC, O32, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<CC>::LDS_BYTES)); \
-            conf = true;                                                                                              \
-        }                                                                                                             \
+        { const int rc_ = pcc_enable_big_lds((const void*)conv_f16_kernel<CC, O32, SUB>, Cfg<CC>::LDS_BYTES); if (rc_ != PCC_OK) return rc_; } \
         hipLaunchKernelGGL((conv_f16_kernel<CC, O32, SUB>), dim3((unsigned)nwg), dim3(256), Cfg<CC>::LDS_BYTES, st, a, nwg); \
     }
     if (sub) {

@@ -1419,15 +1419,7 @@ static Plan make_plan(const pcc_conv_desc* d) {
 
 template <typename KernelT, typename... Extra>
 int launch(KernelT kern, int nt, int lds_bytes, int tiles, const ConvArgs& a, hipStream_t st, Extra... extra) {
-    static thread_local const void* configured[256];
-    static thread_local int nconf = 0;
-    bool done = false;
-    for (int i = 0; i < nconf; ++i) done |= (configured[i] == (const void*)kern);
-    if (!done) {
-        if (lds_bytes > 64 * 1024)
-            PCC_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        if (nconf < 256) configured[nconf++] = (const void*)kern;
-    }
+    { const int rc = pcc_enable_big_lds((const void*)kern, lds_bytes); if (rc != PCC_OK) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(nt), lds_bytes, st, a, extra...);
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;

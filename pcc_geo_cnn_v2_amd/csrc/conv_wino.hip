@@ -445,26 +445,16 @@ int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const f
                                     conv16_wino_kernel<false, true, false>,  conv16_wino_kernel<true, true, false>,
                                     conv16_wino_kernel<false, false, true>,  conv16_wino_kernel<true, false, true>,
                                     conv16_wino_kernel<false, true, true>,   conv16_wino_kernel<true, true, true>};
-    static thread_local bool configured = false;
-    if (!configured) {
-        for (int i = 0; i < 8; ++i)
-            PCC_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        configured = true;
-    }
     // all cin groups of a 64-channel layer in one launch (MULTI) unless the layer clips, its slabs are too short for the U
     // prefetch schedule, or PCC_WINO_PER_GROUP asks for the per-group launches (bit-identical results: tests compare the two).
     // Measured: 64 -> 64 @16^3 x32 173 -> 167 us (launch boundaries); 32 -> 32 @32^3 (two groups) gains nothing and stays per group.
     const bool per_group = getenv("PCC_WINO_PER_GROUP") != nullptr;       // (read per call: a test flips it)
     if (G >= 4 && !(d->flags & PCC_CONV_CLIP01) && a.zlen >= 6 && !per_group) {
         static const kern_t mk[2] = {conv16_wino_kernel<false, false, false, true>, conv16_wino_kernel<true, false, false, true>};
-        static thread_local bool mconf = false;
-        if (!mconf) {
-            for (int i = 0; i < 2; ++i)
-                PCC_CHECK_HIP(hipFuncSetAttribute((const void*)mk[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_MULTI));
-            mconf = true;
-        }
         a.u = u_packed; a.ico = 0; a.ncig = G; a.flags = d->flags;
-        hipLaunchKernelGGL(mk[(d->flags & PCC_CONV_RELU) ? 1 : 0], dim3((unsigned)nwg), dim3(NT), LDS_BYTES_MULTI, st, a, nwg);
+        const kern_t mkern = mk[(d->flags & PCC_CONV_RELU) ? 1 : 0];
+        { const int rc = pcc_enable_big_lds((const void*)mkern, LDS_BYTES_MULTI); if (rc != PCC_OK) return rc; }
+        hipLaunchKernelGGL(mkern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES_MULTI, st, a, nwg);
         PCC_CHECK_HIP(hipGetLastError());
         return PCC_OK;
     }
@@ -476,6 +466,7 @@ int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const f
         a.flags = last ? d->flags : 0;
         const bool relu = last && (d->flags & PCC_CONV_RELU), clip = last && (d->flags & PCC_CONV_CLIP01);
         const kern_t kern = kerns[(relu ? 1 : 0) + (clip ? 2 : 0) + (ci > 0 ? 4 : 0)];
+        { const int rc = pcc_enable_big_lds((const void*)kern, LDS_BYTES); if (rc != PCC_OK) return rc; }
         hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a, nwg);
         PCC_CHECK_HIP(hipGetLastError());
     }
