@@ -42,6 +42,12 @@ def compress(args):
     assert args.resolution > 0, 'resolution must be positive'
     assert args.data_format in ['channels_first', 'channels_last']
     with_normals = args.input_normals is not None
+    # the reference's own default '--opt_metrics d1_psnr' is not in avail_opt_metrics, so its CLI asserts unless the flag is
+    # given (compress_octree.py:37,154).  psnr is monotone in mse (pc_metric.py:55), so '<g>_psnr' is taken as '<g>_mse' here
+    for k, m in enumerate(args.opt_metrics):
+        if m in ('d1_psnr', 'd2_psnr'):
+            args.opt_metrics[k] = m[:3] + 'mse'
+            logger.warning(f"--opt_metrics {m}: not an optimisation metric of the reference; using the equivalent {args.opt_metrics[k]}")
     validate_opt_metrics(args.opt_metrics, with_normals=with_normals)
     files_mult = 1
     if len(args.opt_metrics) > 1:
@@ -148,8 +154,7 @@ def build_parser():
                         help='Decoded files. Allows compression/decompression in a single execution.')
     parser.add_argument('--checkpoint_dir', help='Directory where to save/load model checkpoints.', required=True)
     parser.add_argument('--model_config', help='Model used: c1, c2, c3, c3p.', required=True)
-    # the reference's default 'd1_psnr' is not in avail_opt_metrics, so its CLI asserts unless --opt_metrics is given
-    # (compress_octree.py:156 + utils/pc_metric.py:62-66); kept for identical behaviour -- ev_experiment.py always passes it
+    # the reference's default (compress_octree.py:156); translated to d1_mse in compress(), see there
     parser.add_argument('--opt_metrics', nargs='+', default=['d1_psnr'],
                         help=f'Optimization metrics used. Available: {avail_opt_metrics}')
     parser.add_argument('--max_deltas', nargs='+', default=[np.inf], type=float, help='Max deltas tested during optimization.')

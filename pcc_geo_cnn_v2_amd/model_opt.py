@@ -1,14 +1,28 @@
-"""Per-block threshold search -- same decisions as /root/reference/src/model_opt.py:9-77.
+"""Per-block threshold search -- same decisions as /root/reference/src/model_opt.py:9-77 (pinned by the reference-generated
+fixtures tests/golden/model_opt.npz and model_opt_d2.npz and by the known answers of src/test_model_opt.py).
 
-Host (numpy + KD-tree) restatement used when `fixed_threshold=False`.  The comparisons
-`x_hat > t` are done in float32 like the reference under its pinned numpy 1.18.
+Formulation used here (host AND GPU path): the decoded set at threshold index t is the level set B_t = {v : x_hat(v) >
+thresholds[t]}.  A block is reduced to a TABLE of per-threshold tallies (utils.pc_metric: |B_t| and the D1 / D2 sums in both
+directions) for the leading run of non-empty level sets, plus the tally of the single rounded mean point (the reference's
+failure guard, model_opt.py:59-68).  `select_thresholds_from_stats` then makes every decision (argmin per metric, max_delta
+eligibility, guard) on whole columns of `pc_metric.metrics_table`.  Where the tallies come from is interchangeable:
+
+  * `host_threshold_stats`: KD-trees, used only to obtain nearest-neighbour indices.  The tree over the original points is the
+    same for every threshold, so the B->A neighbours of all voxels are queried ONCE (on B_0, the largest level set) and sliced
+    per threshold; one tree per level set remains for A->B (which neighbour scipy's tree returns among equidistant ones decides
+    the D2 numbers, so that tree must be the one the reference builds: same points, same order, balanced_tree=False);
+  * `ops.d1_threshold_stats` (csrc/threshold_search.hip): exact squared Euclidean distance transforms on the GPU -- D1 only;
+  * both: d1_* columns from the GPU, d2_* columns from the host pool (`HostSearchPool`, groups=('d2',)).
+
+The comparisons `x_hat > t` are done in float32 like the reference under its pinned numpy 1.18.
 """
 import logging
 
 import numpy as np
 from scipy.spatial import cKDTree
 
-from .utils.pc_metric import compute_metrics, validate_opt_metrics
+from .utils import pc_metric as PM
+from .utils.pc_metric import validate_opt_metrics
 
 logger = logging.getLogger(__name__)
 
@@ -20,92 +34,161 @@ def _gt(x_hat, t):
     return x_hat > t
 
 
-def build_points_threshold(x_hat, thresholds, len_block, max_delta=np.inf):
-    pa_list = []
-    for i, t in enumerate(thresholds):
-        pa = np.argwhere(_gt(x_hat, t)).astype('float32')
-        if len(pa) == 0:
+def _level_subsets(x_hat, thresholds):
+    """(cand, [sel_0, sel_1, ...]): `cand` = float32 coordinates of the voxels above the smallest threshold in np.argwhere
+    (lexicographic) order -- the grid is scanned once -- and sel_t = indices into `cand` of the level set {x_hat >
+    thresholds[t]}, for t = 0, 1, ... up to (excluding) the first empty one.  Every level set is an order-preserving subset
+    of `cand`, whatever the order of the thresholds."""
+    x_hat = np.asarray(x_hat)
+    thresholds = np.asarray(thresholds)
+    if len(thresholds) == 0:
+        return np.zeros((0, x_hat.ndim), 'float32'), []
+    cand = np.argwhere(_gt(x_hat, thresholds.min()))
+    vals = x_hat[tuple(cand.T)]
+    subsets = []
+    for thr in thresholds:
+        sel = np.flatnonzero(_gt(vals, thr))
+        if len(sel) == 0:
             break
-        len_ratio = len(pa) / len_block
-        if (1 / max_delta) < len_ratio < max_delta:
-            pa_list.append((i, pa))
-    return pa_list
+        subsets.append(sel)
+    return cand.astype('float32'), subsets
+
+
+def level_sets(x_hat, thresholds):
+    """[(t, points float32 (n, ndim))] for t = 0, 1, ... while the level set {x_hat > thresholds[t]} is non-empty."""
+    cand, subsets = _level_subsets(x_hat, thresholds)
+    return [(t, cand[sel]) for t, sel in enumerate(subsets)]
+
+
+def ratio_eligible(n_b, n_a, max_delta):
+    """model_opt.py:16-17: a decoded set is eligible when 1/max_delta < |B| / |A| < max_delta."""
+    ratio = np.asarray(n_b) / n_a
+    return ((1 / max_delta) < ratio) & (ratio < max_delta)
+
+
+def build_points_threshold(x_hat, thresholds, len_block, max_delta=np.inf):
+    """[(t, points)] of the eligible level sets (the reference's helper, model_opt.py:9-18; known answers in
+    src/test_model_opt.py:12-36)."""
+    return [(t, pts) for t, pts in level_sets(x_hat, thresholds) if ratio_eligible(len(pts), len_block, max_delta)]
+
+
+def metric_names(opt_metrics, max_deltas):
+    return [f'{m}_{d}' for d in max_deltas for m in opt_metrics]
+
+
+def host_threshold_stats(block, x_hat, thresholds, normals=None):
+    """Tallies of every non-empty leading level set of one block against the original points, with KD-trees.
+    Returns (tallies float64[T, 5], mean_tally float64[5]); T = number of leading non-empty level sets."""
+    a = block[:, :3]
+    tree_a = cKDTree(a, balanced_tree=False)
+    cand, subsets = _level_subsets(x_hat, thresholds)
+    tallies = np.zeros((len(subsets), 5), np.float64)
+    cand_to_a = PM.nearest(tree_a, cand) if subsets else None       # B->A: one query serves every threshold
+    for t, sel in enumerate(subsets):
+        b = cand[sel]
+        to_b = PM.nearest(cKDTree(b, balanced_tree=False), a)       # A->B: the reference's tree over B_t
+        tallies[t] = PM.pair_tally(a, b, to_b, cand_to_a[sel], normals)
+    mean_point = np.round(np.mean(a, axis=0))[np.newaxis, :]
+    mean_tally = PM.pair_tally(a, mean_point, np.zeros(len(a), np.int64), PM.nearest(tree_a, mean_point), normals)
+    return tallies, mean_tally
+
+
+def mean_point_d1_tally(block):
+    """D1 tally of the rounded mean point without a KD-tree (which nearest original point is taken does not matter for D1)."""
+    a = np.asarray(block)[:, :3].astype(np.float64)
+    sq = PM.squared_norms(a - np.round(np.mean(a, axis=0)))
+    tally = np.zeros(5, np.float64)
+    tally[PM.N_B], tally[PM.D1_AB], tally[PM.D1_BA] = 1, sq.sum(), sq.min()
+    return tally
+
+
+def select_thresholds_from_stats(n_a, tallies, mean_tally, n_thresholds, resolution, opt_metrics, max_deltas):
+    """Every decision of the reference's search (model_opt.py:33-73) from the per-threshold tallies of one block: for each
+    max_delta the eligible thresholds (all of them when none is eligible or max_delta is None), for each metric the first
+    minimum over those, replaced by the 'emit nothing' index n_thresholds - 1 when the single mean point scores better."""
+    names = metric_names(opt_metrics, max_deltas)
+    nothing = n_thresholds - 1
+    tallies = np.asarray(tallies, np.float64).reshape(-1, 5)
+    if len(tallies) == 0:
+        return names, [nothing] * len(opt_metrics)          # (sic) not x len(max_deltas): model_opt.py:35-36
+    groups = sorted({m.split('_', 1)[0] for m in opt_metrics})
+    table = PM.metrics_table(n_a, tallies, resolution - 1, groups)
+    guard = PM.metrics_table(n_a, mean_tally, resolution - 1, groups)
+    everything = np.arange(len(tallies))
+    best = []
+    for max_delta in max_deltas:
+        pool = everything
+        if max_delta is not None:
+            ok = everything[ratio_eligible(tallies[:, PM.N_B], n_a, max_delta)]
+            pool = ok if len(ok) else everything
+        for m in opt_metrics:
+            column = table[m][pool]
+            k = int(np.argmin(column))
+            best.append(nothing if column[k] > guard[m] else int(pool[k]))
+    return names, best
 
 
 def compute_optimal_thresholds(block, x_hat, thresholds, resolution, normals=None, opt_metrics=['d1_mse'],
                                max_deltas=[np.inf], fixed_threshold=False):
+    """The reference's entry point (model_opt.py:21): (names '{metric}_{max_delta}', threshold index per name)."""
     validate_opt_metrics(opt_metrics, with_normals=normals is not None)
     assert len(max_deltas) > 0
-    best_thresholds = []
-    ret_opt_metrics = [f'{opt_metric}_{max_delta}' for max_delta in max_deltas for opt_metric in opt_metrics]
     if fixed_threshold:
-        half_thr = len(thresholds) // 2
-        return ret_opt_metrics, [half_thr] * len(max_deltas) * len(opt_metrics)
-
-    pa_list = build_points_threshold(x_hat, thresholds, len(block))
-    max_threshold_idx = len(thresholds) - 1
-    if len(pa_list) == 0:
-        return ret_opt_metrics, [max_threshold_idx] * len(opt_metrics)
-
-    t1 = cKDTree(block[:, :3], balanced_tree=False)
-    pa_metrics = [compute_metrics(block[:, :3], pa, resolution - 1, p1_n=normals, t1=t1) for _, pa in pa_list]
-    mean_point = np.round(np.mean(block[:, :3], axis=0))[np.newaxis, :]
-    mean_metrics = compute_metrics(block[:, :3], mean_point, resolution - 1, p1_n=normals, t1=t1)
-
-    for max_delta in max_deltas:
-        cur_pa_list, cur_pa_metrics = pa_list, pa_metrics
-        if max_delta is not None:
-            filt = build_points_threshold(x_hat, thresholds, len(block), max_delta)
-            if len(filt) > 0:
-                cur_pa_list = filt
-                # NOTE: the reference indexes pa_metrics with the THRESHOLD index (model_opt.py:46-47),
-                # which equals the list position because pa_list has no gaps before its first empty set.
-                cur_pa_metrics = [pa_metrics[i] for i, _ in filt]
-        for opt_metric in opt_metrics:
-            best_threshold_idx = int(np.argmin([x[opt_metric] for x in cur_pa_metrics]))
-            cur_best_metric = cur_pa_metrics[best_threshold_idx][opt_metric]
-            # failure case: a single mean point beats the network output -> output no points (:59-68)
-            if cur_best_metric > mean_metrics[opt_metric]:
-                final_idx = max_threshold_idx
-            else:
-                final_idx = cur_pa_list[best_threshold_idx][0]
-            best_thresholds.append(final_idx)
-    assert len(ret_opt_metrics) == len(best_thresholds)
-    return ret_opt_metrics, best_thresholds
+        return metric_names(opt_metrics, max_deltas), [len(thresholds) // 2] * (len(max_deltas) * len(opt_metrics))
+    tallies, mean_tally = host_threshold_stats(block, x_hat, thresholds, normals)
+    return select_thresholds_from_stats(len(block), tallies, mean_tally, len(thresholds), resolution, opt_metrics, max_deltas)
 
 
 class HostSearchPool:
-    """Persistent pool of worker PROCESSES (pcc_geo_cnn_v2_amd.search_worker) for the host KD-tree threshold search: the blocks
-    of a chunk are independent, the reference searches them one after the other (model_types.py:192-212).  Subprocesses
-    with pipes instead of multiprocessing: no fork of a process that holds a HIP context, no re-import of the caller's
-    __main__.  Decisions are those of compute_optimal_thresholds (same code, same scipy)."""
+    """Persistent pool of worker PROCESSES (pcc_geo_cnn_v2_amd.search_worker) for the host KD-tree part of the threshold
+    search: the blocks of a chunk are independent, the reference searches them one after the other (model_types.py:192-212).
+    Subprocesses with pipes instead of multiprocessing: no fork of a process that holds a HIP context, no re-import of the
+    caller's __main__.  A worker that dies is replaced and the failure reported with its exit status."""
 
     def __init__(self, n_workers):
+        self.procs = [self._spawn() for _ in range(max(1, int(n_workers)))]
+
+    @staticmethod
+    def _spawn():
         import os
         import subprocess
         import sys
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), OMP_NUM_THREADS='1')
-        self.procs = [subprocess.Popen([sys.executable, '-m', 'pcc_geo_cnn_v2_amd.search_worker'], stdin=subprocess.PIPE,
-                                       stdout=subprocess.PIPE, env=env) for _ in range(max(1, int(n_workers)))]
+        return subprocess.Popen([sys.executable, '-m', 'pcc_geo_cnn_v2_amd.search_worker'], stdin=subprocess.PIPE,
+                                stdout=subprocess.PIPE, env=env)
 
-    def map(self, jobs):
-        """jobs: list of (block, x_hat, thresholds, resolution, with_normals, opt_metrics, max_deltas).  Returns
-        [(names, best)] in order.  Each worker handles jobs i, i + W, i + 2W, ... through its own pipe."""
+    def _exchange(self, w, job):
         import pickle
         import struct
+        p = self.procs[w]
+        try:
+            data = pickle.dumps(job, protocol=4)
+            p.stdin.write(struct.pack('<Q', len(data)) + data)
+            p.stdin.flush()
+            hdr = p.stdout.read(8)
+            body = p.stdout.read(struct.unpack('<Q', hdr)[0]) if len(hdr) == 8 else b''
+            if len(hdr) < 8 or len(body) < struct.unpack('<Q', hdr)[0]:
+                raise EOFError('short read')
+        except (EOFError, BrokenPipeError, OSError) as e:
+            p.kill()
+            code = p.wait()
+            self.procs[w] = self._spawn()       # the pool stays usable
+            raise RuntimeError(f'threshold search worker {w} died (exit status {code}, {e}); it has been restarted') from e
+        return pickle.loads(body)
+
+    def map(self, jobs):
+        """jobs, each one of
+             ('decide', block, x_hat, thresholds, resolution, with_normals, opt_metrics, max_deltas) -> (names, best)
+             ('tally', block, x_hat, thresholds, with_normals)                                      -> (tallies, mean_tally)
+           (a bare 7-tuple is a 'decide' job).  Results in order; worker i handles jobs i, i + W, ... through its own pipe."""
         from concurrent.futures import ThreadPoolExecutor
         W = len(self.procs)
         out = [None] * len(jobs)
 
         def drive(w):
-            p = self.procs[w]
             for i in range(w, len(jobs), W):
-                data = pickle.dumps(jobs[i], protocol=4)
-                p.stdin.write(struct.pack('<Q', len(data)) + data)
-                p.stdin.flush()
-                n = struct.unpack('<Q', p.stdout.read(8))[0]
-                status, a, b = pickle.loads(p.stdout.read(n))
+                status, a, b = self._exchange(w, jobs[i])
                 if status != 'ok':
                     raise AssertionError(f'threshold search worker: {a}')
                 out[i] = (a, b)
@@ -127,68 +210,53 @@ class HostSearchPool:
         self.close()
 
 
-def select_thresholds_from_stats(block, s_ab, s_ba, n_b, tcount, n_thresholds, resolution, opt_metrics, max_deltas):
-    """The decision logic of compute_optimal_thresholds (model_opt.py:33-73) applied to exact per-threshold D1 sums
-    (integers) of one block, as produced by ops.d1_threshold_stats.  Only d1_* metrics (no normals)."""
-    ret_opt_metrics = [f'{opt_metric}_{max_delta}' for max_delta in max_deltas for opt_metric in opt_metrics]
-    max_threshold_idx = n_thresholds - 1
-    T = int(tcount)                                   # thresholds 0..T-1 have a non-empty decoded set (pa_list)
-    if T == 0:
-        return ret_opt_metrics, [max_threshold_idx] * len(opt_metrics)
-    nA = len(block)
-    sab, sba, nb = s_ab[:T].astype(np.float64), s_ba[:T].astype(np.float64), n_b[:T].astype(np.float64)
-    met = {'d1_sum_AB': sab, 'd1_sum_BA': sba, 'd1_sum_max': np.maximum(sab, sba), 'd1_sum_mean': (sab + sba) / 2,
-           'd1_mse_AB': sab / nA, 'd1_mse_BA': sba / nb}
-    met['d1_mse'] = np.maximum(met['d1_mse_AB'], met['d1_mse_BA'])
-    # single mean point (failure guard, :59-68)
-    pts = np.asarray(block)[:, :3].astype(np.float64)
-    mp = np.round(np.mean(pts, axis=0))
-    d = np.sum((pts - mp) ** 2, axis=1)
-    m_ab, m_ba = float(np.sum(d)), float(np.min(d))
-    mean_met = {'d1_sum_AB': m_ab, 'd1_sum_BA': m_ba, 'd1_sum_max': max(m_ab, m_ba), 'd1_sum_mean': (m_ab + m_ba) / 2,
-                'd1_mse_AB': m_ab / nA, 'd1_mse_BA': m_ba / 1.0}
-    mean_met['d1_mse'] = max(mean_met['d1_mse_AB'], mean_met['d1_mse_BA'])
-    best_thresholds = []
-    for max_delta in max_deltas:
-        idxs = np.arange(T)
-        if max_delta is not None:
-            ratio = nb / nA
-            elig = idxs[((1 / max_delta) < ratio) & (ratio < max_delta)]
-            if len(elig) > 0:
-                idxs = elig
-        for opt_metric in opt_metrics:
-            vals = met[opt_metric][idxs]
-            j = int(np.argmin(vals))
-            if vals[j] > mean_met[opt_metric]:
-                best_thresholds.append(max_threshold_idx)
-            else:
-                best_thresholds.append(int(idxs[j]))
-    return ret_opt_metrics, best_thresholds
+def gpu_search_supported(opt_metrics, dhw):
+    """The GPU distance-transform search covers the d1_* metrics of grids up to 128^3, with or without normals in the input."""
+    return max(dhw) <= 128 and any(m.startswith('d1_') for m in opt_metrics)
 
 
-def gpu_search_supported(opt_metrics, normals, dhw):
-    return normals is None and all(m.startswith('d1_') for m in opt_metrics) and max(dhw) <= 128
-
-
-def compute_optimal_thresholds_gpu(ctx, blocks, x_hat, thresholds, resolution, opt_metrics=('d1_mse',),
-                                   max_deltas=(np.inf,)):
-    """compute_optimal_thresholds for a batch of blocks with all KD-tree work replaced by exact distance transforms on
-    the GPU.  blocks: list of (n_i, >=3) arrays; x_hat: (B,D,H,W) float32 device tensor (clipped inside, like
-    model_types.py:202).  Returns (ret_opt_metrics, [best thresholds per block])."""
+def d1_tallies_gpu(ctx, blocks, x_hat, thresholds):
+    """Per-block D1 tallies from exact distance transforms on the GPU (csrc/threshold_search.hip).  blocks: list of
+    (n_i, >=3) arrays; x_hat: (B,D,H,W) float32 device tensor (clipped inside, like model_types.py:202).
+    Returns [float64[T_i, 5]] -- the d2 slots are zero."""
     import torch
     from . import ops
-    from .utils.pc_metric import validate_opt_metrics
-    validate_opt_metrics(opt_metrics, with_normals=False)
-    B = len(blocks)
     # C-contiguous (n,3): np.argwhere-style inputs are transposed views and would otherwise stay Fortran-ordered
     pts = np.ascontiguousarray(np.concatenate([np.asarray(b)[:, :3] for b in blocks]).astype(np.uint32).astype(np.int32))
     bof = np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(blocks)])
     thr = torch.from_numpy(np.asarray(thresholds).astype(np.float32)).to(ctx.device)
     s_ab, s_ba, n_b, tcount = ops.d1_threshold_stats(ctx, x_hat, thr, torch.from_numpy(pts).to(ctx.device),
                                                      torch.from_numpy(bof).to(ctx.device), clip=True)
+    out = []
+    for i in range(len(blocks)):
+        T = int(tcount[i])
+        t = np.zeros((T, 5), np.float64)
+        t[:, PM.N_B], t[:, PM.D1_AB], t[:, PM.D1_BA] = n_b[i][:T], s_ab[i][:T], s_ba[i][:T]
+        out.append(t)
+    return out
+
+
+def compute_optimal_thresholds_gpu(ctx, blocks, x_hat, thresholds, resolution, opt_metrics=('d1_mse',),
+                                   max_deltas=(np.inf,), d2_stats=None):
+    """compute_optimal_thresholds for a batch of blocks with the KD-tree work of the d1_* metrics replaced by exact distance
+    transforms on the GPU.  `d2_stats`: per block (tallies, mean_tally) from the host pool when d2_* metrics are requested --
+    or a callable returning that list, evaluated after the GPU work has been issued so both run concurrently (their D2 slots
+    are merged into the GPU's table; the D1 slots of both sources are the same integers, which is asserted).
+    Returns (names, [best thresholds per block])."""
+    validate_opt_metrics(opt_metrics, with_normals=d2_stats is not None)
+    d1 = d1_tallies_gpu(ctx, blocks, x_hat, thresholds)
+    if callable(d2_stats):
+        d2_stats = d2_stats()
     names, best = None, []
-    for i in range(B):
-        names, bt = select_thresholds_from_stats(blocks[i], s_ab[i], s_ba[i], n_b[i], tcount[i], len(thresholds),
-                                                 resolution, list(opt_metrics), list(max_deltas))
+    for i, blk in enumerate(blocks):
+        tallies, mean_tally = d1[i], mean_point_d1_tally(blk)
+        if d2_stats is not None:
+            host_t, host_mean = d2_stats[i]
+            assert len(host_t) == len(tallies), 'host and GPU disagree on the number of non-empty level sets'
+            assert np.array_equal(host_t[:, :3], tallies[:, :3]), 'host KD-tree and GPU distance-transform D1 sums differ'
+            tallies[:, [PM.D2_AB, PM.D2_BA]] = host_t[:, [PM.D2_AB, PM.D2_BA]]
+            mean_tally[[PM.D2_AB, PM.D2_BA]] = host_mean[[PM.D2_AB, PM.D2_BA]]
+        names, bt = select_thresholds_from_stats(len(blk), tallies, mean_tally, len(thresholds), resolution,
+                                                 list(opt_metrics), list(max_deltas))
         best.append(bt)
     return names, best

@@ -10,60 +10,83 @@ AssertionError in `load_compressed_file` (pinned by src/test_model_syntax.py:22-
 (default) reproduces exactly that; `strict=True` (used by our CLI) raises AssertionError at save time.
 """
 import logging
+import struct
 
 import numpy as np
 
 logger = logging.getLogger(__name__)
 
 
+_HEADER = struct.Struct('<HBHBH')        # resolution, octree level, n_blocks, strings per block, len(binstr)
+_U16 = struct.Struct('<H')
+
+
+def _field(value, bits, strict, what):
+    """An unsigned `bits`-wide field.  A value that does not fit wraps modulo 2**bits -- what the reference's numpy 1.18 casts
+    did silently -- or, with strict=True, is an AssertionError here at save time."""
+    value = int(value)
+    if not 0 <= value < (1 << bits):
+        assert not strict, f'Overflow/underflow: {what} = {value} does not fit {bits} bits'
+        logger.warning('%s = %s does not fit %d bits: wrapping like numpy 1.18 did for the reference', what, value, bits)
+        value &= (1 << bits) - 1
+    return value
+
+
 def to_bytes(x, dtype, strict=False):
-    iinfo = np.iinfo(dtype)
-    x64 = np.array(x, dtype=np.int64)
-    bad = np.any(x64 > iinfo.max) or np.any(x64 < iinfo.min)
-    if bad:
-        assert not strict, f'Overflow/underflow {x} {iinfo}'
-        logger.warning('value %s does not fit %s: wrapping like numpy 1.18 did for the reference', x, dtype)
-    return (x64 & ((1 << iinfo.bits) - 1)).astype(np.uint64).astype(dtype).tobytes()
+    """Little-endian bytes of a sequence of unsigned integers of numpy `dtype` (uint8 / uint16), see `_field`."""
+    width = np.dtype(dtype).itemsize
+    return b''.join(_field(v, 8 * width, strict, 'value').to_bytes(width, 'little') for v in np.asarray(x).reshape(-1).tolist())
 
 
 def scalar_to_bytes(x, dtype, strict=False):
     return to_bytes([x], dtype, strict)
 
 
-def read_from_buffer(f, n, dtype):
-    return np.frombuffer(f.read(int(np.dtype(dtype).itemsize * n)), dtype=dtype)
-
-
 def save_compressed_file(binstr, data_b_list, resolution, octree_level, strict=False):
-    """Saves an octree partitioned point cloud and its partition bitstreams as an unified bitstream"""
-    ret = [scalar_to_bytes(resolution, np.uint16, strict), scalar_to_bytes(octree_level, np.uint8, strict),
-           scalar_to_bytes(len(data_b_list), np.uint16, strict),
-           scalar_to_bytes(len(data_b_list[0][0]), np.uint8, strict),
-           scalar_to_bytes(len(binstr), np.uint16, strict), to_bytes(binstr, np.uint8, strict)]
-    for strings, best_threshold_idx in data_b_list:
-        ret.append(scalar_to_bytes(best_threshold_idx, np.uint8, strict))
-        for s in strings:
-            ret.append(scalar_to_bytes(len(s), np.uint16, strict))
-            ret.append(bytes(s))
-    return b''.join(ret)
+    """Serialises an octree-partitioned cloud: the partition bits `binstr` and, per block, (strings, threshold index) -- byte
+    for byte the file of the reference's writer (model_syntax.py:20-35; pinned by tests/golden/model_syntax.npz)."""
+    out = bytearray(_HEADER.pack(_field(resolution, 16, strict, 'resolution'), _field(octree_level, 8, strict, 'octree level'),
+                                 _field(len(data_b_list), 16, strict, 'number of blocks'),
+                                 _field(len(data_b_list[0][0]), 8, strict, 'strings per block'),
+                                 _field(len(binstr), 16, strict, 'len(binstr)')))
+    out += bytes(_field(b, 8, strict, 'binstr entry') for b in binstr)
+    for strings, threshold_idx in data_b_list:
+        out.append(_field(threshold_idx, 8, strict, 'threshold index'))
+        for payload in strings:
+            out += _U16.pack(_field(len(payload), 16, strict, 'string length'))
+            out += payload
+    return bytes(out)
+
+
+class _Cursor:
+    """Bounds-checked reader over the whole container held in memory."""
+
+    def __init__(self, raw):
+        self.raw, self.pos = memoryview(raw), 0
+
+    def take(self, n):
+        end = self.pos + n
+        if end > len(self.raw):
+            # the reference indexes an empty np.frombuffer result here (model_syntax.py:41-52): IndexError
+            raise IndexError(f'compressed file truncated: need {end} bytes, have {len(self.raw)}')
+        chunk, self.pos = self.raw[self.pos:end], end
+        return chunk
+
+    def unpack(self, fmt):
+        return fmt.unpack(self.take(fmt.size))
 
 
 def load_compressed_file(f):
-    """Loads an octree partitioned point cloud unified bitstream"""
+    """Parses the container written by save_compressed_file (layout in the module docstring; the reference's reader is
+    model_syntax.py:38-58).  `f`: binary file object.  Returns (resolution, level, binstr uint8 array, [(strings, threshold
+    index)]); bytes left over after the last block are an AssertionError like in the reference."""
+    cur = _Cursor(f.read())
+    resolution, level, n_blocks, per_block, n_binstr = cur.unpack(_HEADER)
+    binstr = np.frombuffer(cur.take(n_binstr), dtype=np.uint8)
     blocks = []
-    resolution = read_from_buffer(f, 1, np.uint16)[0]
-    level = read_from_buffer(f, 1, np.uint8)[0]
-    n_blocks = read_from_buffer(f, 1, np.uint16)[0]
-    n_strings = read_from_buffer(f, 1, np.uint8)[0]
-    n_binstr = read_from_buffer(f, 1, np.uint16)[0]
-    binstr = read_from_buffer(f, n_binstr, np.uint8)
-    for _ in range(n_blocks):
-        best_threshold_idx = read_from_buffer(f, 1, np.uint8)[0]
-        strings = []
-        for _i in range(n_strings):
-            n_bytes = read_from_buffer(f, 1, np.uint16)[0]
-            strings.append(f.read(int(n_bytes)))
-        blocks.append((strings, best_threshold_idx))
-    file_end = f.read()
-    assert file_end == b'', f'File not read completely file_end {file_end[:64]}'
+    while len(blocks) < n_blocks:
+        threshold_idx = cur.take(1)[0]
+        blocks.append(([bytes(cur.take(cur.unpack(_U16)[0])) for _ in range(per_block)], threshold_idx))
+    rest = bytes(cur.raw[cur.pos:])
+    assert not rest, f'File not read completely file_end {rest[:64]}'
     return resolution, level, binstr, blocks

@@ -25,10 +25,10 @@ from . import _lib as L
 from . import model_transforms as MT
 from . import ops
 from .entropy_models import EntropyBottleneck, GaussianConditional, scale_table
-from .model_opt import compute_optimal_thresholds, compute_optimal_thresholds_gpu, gpu_search_supported
+from .model_opt import compute_optimal_thresholds_gpu, gpu_search_supported, metric_names
 from .model_transforms import TransformType
 from .utils.octree_coding import departition_octree
-from .utils.pc_metric import compute_metrics
+from .utils.pc_metric import cloud_metrics_batch
 
 logger = logging.getLogger(__name__)
 
@@ -36,51 +36,57 @@ CHECKPOINT_FILE = 'model.npz'
 
 
 def sparse_to_dense(block, x_shape, data_format):
-    """Host version kept for API parity (model_types.py:108-114); the codec uses ops.voxelize."""
-    x_val = np.zeros(x_shape, dtype=np.float32)
-    block = np.asarray(block).astype(np.uint32)
-    if data_format == 'channels_first':
-        x_val[0, 0, block[:, 0], block[:, 1], block[:, 2]] = 1.0
-    else:
-        x_val[0, block[:, 0], block[:, 1], block[:, 2], 0] = 1.0
-    return x_val
+    """Host version of the dense occupancy scatter (model_types.py:108-114), kept for API parity and as the test oracle of
+    ops.voxelize, which the codec uses.  x_shape is the 5-D shape of ONE block in `data_format`."""
+    assert data_format in ('channels_first', 'channels_last')
+    grid = np.zeros(x_shape, dtype=np.float32)
+    occupancy = grid[0, 0] if data_format == 'channels_first' else grid[0, ..., 0]      # (D, H, W) view of the single channel
+    occupancy[tuple(np.asarray(block)[:, :3].astype(np.uint32).T)] = 1.0                 # out-of-range coordinate: IndexError
+    return grid
 
 
 def get_normals_if(x, with_normals):
     return x[:, x.shape[1] - 3:x.shape[1]] if with_normals else None
 
 
+def rank_candidates(names, cand_metrics, opt_groups=('d1', 'd2')):
+    """The selection rule of model_types.py:128-176 on already-computed metrics: per optimisation group ('d1', 'd2') the
+    candidate -- among those whose metric name starts with the group -- with the highest '{group}_psnr'; an empty decoded
+    cloud (metrics None) scores -inf.  Returns [(group, winning candidate index, its metrics)].  Shared by the single-process
+    and the sharded encoder (the latter feeds all_reduce'd metrics, so every rank takes the same decision)."""
+    picks = []
+    for group in opt_groups:
+        members = [i for i, n in enumerate(names) if n.startswith(group)]
+        if not members:
+            continue
+        key = f'{group}_psnr'
+        score = {i: (-np.inf if cand_metrics[i] is None else cand_metrics[i][key]) for i in members}
+        winner = members[int(np.argmax([score[i] for i in members]))]
+        picks.append((group, winner, cand_metrics[winner] if cand_metrics[winner] is not None else {key: -np.inf}))
+        logger.info(f'Group {group} : {key} best idx {winner} {names[winner]}\n' +
+                    pprint.pformat({names[i]: f'{score[i]:.2f}' for i in members}))
+    return picks
+
+
 def select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics, points, resolution, with_normals,
                                opt_groups=('d1', 'd2')):
-    """Selects best opt_metric for each opt_group (model_types.py:128-176)."""
+    """Per optimisation group, which candidate reconstruction of the whole cloud to keep (the reference's function of the same
+    name, model_types.py:128-176; results pinned by tests/golden/select_best.npz).  x_hat_list[m] = the decoded blocks of
+    candidate m (block-local coordinates).  Returns one dict per non-empty group: 'idx', 'metrics', 'x_hat_list',
+    'blocks_depart' (blocks in cloud coordinates), 'blocks_full' (one array)."""
     assert len(opt_metrics) == len(x_hat_list), f'lengths of opt_metrics {len(opt_metrics)} and x_hat_list' + \
                                                 f' {len(x_hat_list)} should be equal'
-    om_groups = [[(x, y, i) for i, (x, y) in enumerate(zip(opt_metrics, x_hat_list))
-                  if x.startswith(group)] for group in opt_groups]
-    bbox_min = [0, 0, 0]
-    bbox_max = [resolution] * 3
-    t1 = cKDTree(points[:, :3])
-    metadata = []
-    for group, om_group in zip(opt_groups, om_groups):
-        metric_key = f'{group}_psnr'
-        if len(om_group) == 0:
-            continue
-        om_names, cur_x_hat_list, indexes = zip(*om_group)
-        cur_blocks_depart = [departition_octree(x, binstr, bbox_min, bbox_max, level) for x in cur_x_hat_list]
-        cur_blocks_full = [np.vstack(x) for x in cur_blocks_depart]
-        cur_metrics_full = [compute_metrics(points[:, :3], x, resolution - 1, p1_n=get_normals_if(points, with_normals),
-                                            t1=t1) if len(x) else {metric_key: -np.inf} for x in cur_blocks_full]
-        cur_metrics = [x[metric_key] for x in cur_metrics_full]
-        local_best_idx = int(np.argmax(cur_metrics))
-        best_idx = indexes[local_best_idx]
-        metadata.append({'idx': best_idx,
-                         'metrics': cur_metrics_full[local_best_idx],
-                         'x_hat_list': cur_x_hat_list[local_best_idx],
-                         'blocks_depart': cur_blocks_depart[local_best_idx],
-                         'blocks_full': cur_blocks_full[local_best_idx]})
-        logger.info(f'Group {group} : {metric_key} best idx {best_idx} {opt_metrics[best_idx]}\n' +
-                    pprint.pformat(dict(zip(om_names, [f"{x:.2f}" for x in cur_metrics]))))
-    return metadata
+    grouped = [m for m, n in enumerate(opt_metrics) if any(n.startswith(g) for g in opt_groups)]
+    placed = {m: departition_octree(x_hat_list[m], binstr, [0, 0, 0], [resolution] * 3, level) for m in grouped}
+    clouds = {m: np.vstack(placed[m]) for m in grouped}
+    original = points[:, :3]
+    scored = cloud_metrics_batch(original, [clouds[m] for m in grouped], resolution - 1, get_normals_if(points, with_normals),
+                                 cKDTree(original))
+    cand_metrics = [None] * len(opt_metrics)
+    for m, met in zip(grouped, scored):
+        cand_metrics[m] = met
+    return [{'idx': m, 'metrics': met, 'x_hat_list': x_hat_list[m], 'blocks_depart': placed[m], 'blocks_full': clouds[m]}
+            for _, m, met in rank_candidates(opt_metrics, cand_metrics, opt_groups)]
 
 
 class _Pinned:
@@ -114,6 +120,13 @@ class CompressionModel:
         self._host_cache = {}
 
     # ------------------------------------------------------------------ helpers
+    def _bind_transforms(self, **kinds):
+        """`<kind>_transform_class` from the TransformType members of the ctor; `<kind>_transform` (the instance) is created by
+        compress() / decompress()."""
+        for kind, member in kinds.items():
+            setattr(self, f'{kind}_transform_class', member.value)
+            setattr(self, f'{kind}_transform', None)
+
     def _ctx(self, sess):
         ctx = sess if isinstance(sess, (ops.Context, ops._ContextView)) else ops.get_context(None)
         # BASELINE.json configs[4]: the fp16 mode.  Encoder and decoder must agree on it (the decoder recomputes sigma_hat):
@@ -237,7 +250,9 @@ class CompressionModel:
             v2 = isinstance(self, CompressionModelV2)
             med = self._dev(ctx, 'medians', self.entropy_bottleneck.medians)
             tab = self._dev(ctx, 'scale_table', self.conditional_bottleneck.scale_table_f32) if v2 else None
-            self._codec_cache = (key, ops.codec_desc(ctx, 2 if v2 else 1, self.num_filters, nets, med, tab, self.round_mode))
+            # the NetworkWeights objects are kept alive with the entry: their id()s are the key and must not be recycled
+            self._codec_cache = (key, ops.codec_desc(ctx, 2 if v2 else 1, self.num_filters, nets, med, tab, self.round_mode),
+                                 list(nets.values()))
         return self._codec_cache[1][0]
 
     def _gather_points(self, xyz, counts, ctx=None, ready=None):
@@ -274,6 +289,13 @@ class CompressionModel:
         for prefix, tr, cin in self._transforms():
             MT.init_transform(tr, cin, rng)
         self._init_entropy(None)
+        self._drop_device_state()
+
+    def _drop_device_state(self):
+        """Everything on the GPU that was derived from the weights / entropy tables (new ones have just been set): the cached
+        medians / scale table tensors and the pcc_codec_desc, which holds raw device pointers to them."""
+        self._dev_cache.clear()
+        self._codec_cache = (None,)
 
     def get_weights(self):
         out = {}
@@ -286,7 +308,7 @@ class CompressionModel:
         for prefix, tr, _ in self._transforms():
             MT.set_weights(tr, prefix, params)
         self._init_entropy(params)
-        self._dev_cache.clear()
+        self._drop_device_state()
 
     def save_checkpoint(self, checkpoint_dir):
         os.makedirs(checkpoint_dir, exist_ok=True)
@@ -315,7 +337,7 @@ class CompressionModel:
         ctx = self._ctx(sess)
         dhw = self._spatial(self.x_shape)
         strings_list, threshold_list, debug_t_list, x_hat_list = [], [], [], []
-        opt_metrics_ret = [f'{m}_{d}' for d in max_deltas for m in opt_metrics]
+        opt_metrics_ret = metric_names(opt_metrics, max_deltas)
         half = len(self.thresholds) // 2
         for c0 in range(0, len(blocks), self.batch_size):
             chunk = blocks[c0:c0 + self.batch_size]
@@ -331,39 +353,50 @@ class CompressionModel:
                 for j in range(len(chunk)):
                     threshold_list.append([half] * n_m)
                     x_hat_list.append([pts[j]] * n_m)
-            elif gpu_search_supported(opt_metrics, get_normals_if(chunk[0], with_normals), dhw):
-                # adaptive search on the GPU: exact distance transforms instead of <= 255 KD-trees per block
-                opt_metrics_ret, best_all = compute_optimal_thresholds_gpu(ctx, chunk, x_hat, self.thresholds, resolution,
-                                                                          opt_metrics, max_deltas)
+            else:
+                # adaptive search (model_opt.py:33-73).  d1_* metrics: exact distance transforms on the GPU, with or without
+                # normals in the input.  d2_* metrics: the reference's numbers depend on WHICH of several equidistant nearest
+                # neighbours scipy's KD-tree returns (measured: another tie rule moves d2_mse by up to 60 % and the chosen
+                # threshold in 2 of 6 blocks), so those tallies come from the same KD-trees on the host -- one block per
+                # worker process of a persistent pool (the reference runs the blocks one after the other), concurrently
+                # with the GPU's d1 search; the decisions are taken on the merged table.
+                n_m = len(max_deltas) * len(opt_metrics)
+                want_d2 = any(m.startswith('d2_') for m in opt_metrics)
+                on_gpu = gpu_search_supported(opt_metrics, dhw)
+                strings = enc['finish']()
+                host_future = None
+                if want_d2 or not on_gpu:
+                    from concurrent.futures import ThreadPoolExecutor
+                    xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)
+                    # blocks go over in their own dtype: the worker computes exactly what the in-process call would
+                    if on_gpu:
+                        jobs = [('tally', np.ascontiguousarray(chunk[j]), xh[j], self.thresholds, True) for j in range(len(chunk))]
+                    else:
+                        jobs = [('decide', np.ascontiguousarray(chunk[j]), xh[j], self.thresholds, resolution, with_normals,
+                                 list(opt_metrics), list(max_deltas)) for j in range(len(chunk))]
+                    self.host_search_jobs = getattr(self, 'host_search_jobs', 0) + len(jobs)
+                    self.last_host_job_kind = jobs[0][0] if jobs else None
+                    if not hasattr(self, '_search_thread'):
+                        self._search_thread = ThreadPoolExecutor(max_workers=1)
+                    host_future = self._search_thread.submit(self._search_pool(len(chunk)).map, jobs)
+                if on_gpu:
+                    opt_metrics_ret, best_all = compute_optimal_thresholds_gpu(
+                        ctx, chunk, x_hat, self.thresholds, resolution, opt_metrics, max_deltas,
+                        d2_stats=host_future.result if host_future is not None else None)
+                else:
+                    res = host_future.result()
+                    opt_metrics_ret, best_all = res[0][0], [bt for _, bt in res]
                 # a block whose decode is empty at every threshold returns len(opt_metrics) entries (model_opt.py:35-36); with
                 # more than one max_delta the reference's zip(*...) would silently drop the other candidates of the WHOLE
                 # cloud -- here the 'emit nothing' index is repeated instead
-                n_m = len(max_deltas) * len(opt_metrics)
                 best_all = [list(bt) + [bt[-1]] * (n_m - len(bt)) for bt in best_all]
                 per_metric = []
                 for m in range(n_m):
                     xyz, counts = self._extract_points(ctx, x_hat, [bt[m] for bt in best_all], clip=True)
                     per_metric.append(self._gather_points(xyz, counts))
-                strings = enc['finish']()
                 for j in range(len(chunk)):
                     threshold_list.append(list(best_all[j]))
                     x_hat_list.append([per_metric[m][j] for m in range(n_m)])
-            else:
-                # D2 / normals: the reference's numbers depend on WHICH of several equidistant nearest neighbours scipy's
-                # KD-tree returns (measured: another tie rule moves d2_mse by up to 60 % and the chosen threshold in 2 of 6
-                # blocks), so identical decisions need the same KD-tree: host path, one block per host thread (the KD-tree
-                # per worker process of a persistent pool; the reference runs the blocks one after the other, model_types.py:192-212)
-                strings = enc['finish']()
-                xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)
-
-                n_m = len(max_deltas) * len(opt_metrics)
-                jobs = [(np.asarray(chunk[j], np.float64), xh[j], self.thresholds, resolution, with_normals, list(opt_metrics),
-                         list(max_deltas)) for j in range(len(chunk))]
-                for j, (names, best) in enumerate(self._search_pool(len(chunk)).map(jobs)):
-                    opt_metrics_ret = names
-                    best = list(best) + [best[-1]] * (n_m - len(best))     # see above
-                    threshold_list.append(best)
-                    x_hat_list.append([np.argwhere(xh[j] > self._thr32(t)).astype(np.float32) for t in best])
             strings_list.extend(strings)
             debug_t_list.extend(enc['debug'])
         return strings_list, threshold_list, x_hat_list, opt_metrics_ret, debug_t_list
@@ -400,45 +433,40 @@ class CompressionModel:
         n_str = 1 if isinstance(self, CompressionModelV1) else 2
         n_m = len(max_deltas) * len(opt_metrics)
         if names is None or not len(blocks[lo:hi]):
-            names = [f'{m}_{d}' for d in max_deltas for m in opt_metrics]
+            names = metric_names(opt_metrics, max_deltas)
         # (1) one int64 row per block: string lengths, threshold index and candidate point count per metric
         rows = np.zeros((hi - lo, n_str + 2 * n_m), np.int64)
         for j in range(hi - lo):
             rows[j, :n_str] = [len(x) for x in strings_l[j]]
             rows[j, n_str:n_str + n_m] = thr_l[j][:n_m]
             rows[j, n_str + n_m:] = [len(x) for x in xhat_l[j][:n_m]]
-        table = sharding.all_gather_rows(rows)
+        per_rank = sharding.shard_sizes(len(blocks), world)      # known to every rank: no size exchange anywhere below
+        table = sharding.all_gather_rows(rows, counts=per_rank)
         assert table.shape[0] == len(blocks)
-        # (2) the strings: one padded uint8 gather to rank 0
-        blobs = sharding.gather_bytes(b''.join(x for ss in strings_l for x in ss))
-        # (3) D1/D2 of every candidate from per-rank partial sums; the selection is replicated (all_reduce)
+        first = np.concatenate([[0], np.cumsum(per_rank)])
+        # (2) the strings: one padded uint8 gather to rank 0 (payload sizes follow from the table)
+        blobs = sharding.gather_bytes(b''.join(x for ss in strings_l for x in ss),
+                                      counts=[int(table[first[r]:first[r + 1], :n_str].sum()) for r in range(world)])
+        # (3) D1/D2 of every candidate from per-rank partial tallies (one MIN + one SUM all_reduce for all candidates); the
+        # selection is replicated
         origins = block_origins(binstr, [0, 0, 0], [resolution] * 3, level)[lo:hi]
         p1, p1_n = points[:, :3], get_normals_if(points, with_normals)
-        t1 = cKDTree(p1)
         cand_global = []
         for m in range(n_m):
             parts = [np.asarray(xhat_l[j][m], np.float64).reshape(-1, 3) + np.asarray(origins[j], np.float64) for j in range(hi - lo)]
             cand_global.append(np.vstack(parts) if parts else np.zeros((0, 3)))
-        cand_metrics = [sharding.sharded_metrics(p1, cand_global[m], resolution - 1, p1_n, t1) for m in range(n_m)]
-        metadata = []
-        for group in ('d1', 'd2'):
-            idxs = [i for i, nm in enumerate(names) if nm.startswith(group)]
-            if not idxs:
-                continue
-            key = f'{group}_psnr'
-            cur = [cand_metrics[i] if cand_metrics[i] is not None else {key: -np.inf} for i in idxs]
-            best = idxs[int(np.argmax([c[key] for c in cur]))]
-            metadata.append({'idx': best, 'metrics': cand_metrics[best] if cand_metrics[best] is not None else {key: -np.inf}})
-            logger.info(f'Group {group} : {key} best idx {best} {names[best]}\n' +
-                        pprint.pformat({names[i]: f"{c[key]:.2f}" for i, c in zip(idxs, cur)}))
+        cand_metrics = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, cKDTree(p1), sharding.RankGroup())
+        metadata = [{'idx': m, 'metrics': met} for _, m, met in rank_candidates(names, cand_metrics)]
         # (4) the reconstruction of the selected candidates on rank 0 (only for --dec_files / --debug)
         if need_points:
             for md in metadata:
                 m = md['idx']
+                n_pts = table[:, n_str + n_m + m]
                 flat = sharding.gather_rows(np.vstack([np.asarray(xhat_l[j][m], np.float32).reshape(-1, 3) for j in range(hi - lo)])
-                                            if hi > lo else np.zeros((0, 3), np.float32))
+                                            if hi > lo else np.zeros((0, 3), np.float32),
+                                            counts=[int(n_pts[first[r]:first[r + 1]].sum()) for r in range(world)])
                 if rank == 0:
-                    off = np.concatenate([[0], np.cumsum(table[:, n_str + n_m + m])])
+                    off = np.concatenate([[0], np.cumsum(n_pts)])
                     md['x_hat_list'] = tuple(flat[off[j]:off[j + 1]] for j in range(len(blocks)))
                     md['blocks_depart'] = departition_octree(md['x_hat_list'], binstr, [0, 0, 0], [resolution] * 3, level)
                     md['blocks_full'] = np.vstack(md['blocks_depart'])
@@ -530,8 +558,11 @@ class CompressionModel:
                 local, dbg = self.decompress_blocks(sess, blocks[lo:hi], x_shape, debug)
             finally:
                 self._in_shard = False
-            counts = sharding.all_gather_rows(np.array([[len(b)] for b in local], np.int64).reshape(-1, 1))[:, 0]
-            flat = sharding.gather_rows(np.vstack(local).astype(np.float32) if len(local) else np.zeros((0, 3), np.float32))
+            per_rank = sharding.shard_sizes(len(blocks), world)
+            first = np.concatenate([[0], np.cumsum(per_rank)])
+            counts = sharding.all_gather_rows(np.array([[len(b)] for b in local], np.int64).reshape(-1, 1), counts=per_rank)[:, 0]
+            flat = sharding.gather_rows(np.vstack(local).astype(np.float32) if len(local) else np.zeros((0, 3), np.float32),
+                                        counts=[int(counts[first[r]:first[r + 1]].sum()) for r in range(world)])
             if rank != 0:
                 return None, dbg
             off = np.concatenate([[0], np.cumsum(counts)])
@@ -566,9 +597,7 @@ class CompressionModelV1(CompressionModel):
                  analysis_transform_type=TransformType.AnalysisTransformV1,
                  synthesis_transform_type=TransformType.SynthesisTransformV1, *args, **kwargs):
         self.num_filters = num_filters
-        self.analysis_transform_class = analysis_transform_type.value
-        self.synthesis_transform_class = synthesis_transform_type.value
-        self.analysis_transform = self.synthesis_transform = None
+        self._bind_transforms(analysis=analysis_transform_type, synthesis=synthesis_transform_type)
         self.entropy_bottleneck = None
         super().__init__(*args, **kwargs)
 
@@ -682,13 +711,9 @@ class CompressionModelV2(CompressionModel):
                  hyper_synthesis_transform_type=TransformType.HyperSynthesisTransform,
                  scales_min=0.11, scales_max=256, scales_levels=64, *args, **kwargs):
         self.num_filters = num_filters
-        self.analysis_transform_class = analysis_transform_type.value
-        self.synthesis_transform_class = synthesis_transform_type.value
-        self.hyper_analysis_transform_class = hyper_analysis_transform_type.value
-        self.hyper_synthesis_transform_class = hyper_synthesis_transform_type.value
+        self._bind_transforms(analysis=analysis_transform_type, synthesis=synthesis_transform_type,
+                              hyper_analysis=hyper_analysis_transform_type, hyper_synthesis=hyper_synthesis_transform_type)
         self.scale_table = scale_table(scales_min, scales_max, scales_levels)
-        self.analysis_transform = self.synthesis_transform = None
-        self.hyper_analysis_transform = self.hyper_synthesis_transform = None
         self.entropy_bottleneck = self.conditional_bottleneck = None
         super().__init__(*args, **kwargs)
 

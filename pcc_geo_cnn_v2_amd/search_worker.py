@@ -1,26 +1,38 @@
-"""Worker process of model_opt.HostSearchPool: reads pickled jobs (length-prefixed) from stdin, runs the reference's KD-tree
-threshold search (model_opt.compute_optimal_thresholds == /root/reference/src/model_opt.py:21-77) and writes the pickled result
-to stdout.  Plain numpy / scipy: no GPU, no torch."""
+"""Worker process of model_opt.HostSearchPool: reads pickled jobs (length-prefixed) from stdin, runs the host KD-tree part of
+the threshold search (model_opt.compute_optimal_thresholds / host_threshold_stats) and writes the pickled result to the pipe
+that was its stdout.  Plain numpy / scipy: no GPU, no torch."""
+import os
 import pickle
 import struct
 import sys
 
 
 def main():
-    import numpy as np
-    from pcc_geo_cnn_v2_amd.model_opt import compute_optimal_thresholds
-    rd, wr = sys.stdin.buffer, sys.stdout.buffer
+    # the binary protocol owns the original stdout; anything printed from here on goes to stderr and cannot corrupt it
+    wr = os.fdopen(os.dup(sys.stdout.fileno()), 'wb')
+    os.dup2(sys.stderr.fileno(), sys.stdout.fileno())
+    sys.stdout = sys.stderr
+    from pcc_geo_cnn_v2_amd.model_opt import compute_optimal_thresholds, host_threshold_stats
+    rd = sys.stdin.buffer
+
+    def normals_of(block, with_normals):
+        return block[:, block.shape[1] - 3:] if with_normals else None
+
     while True:
         hdr = rd.read(8)
         if len(hdr) < 8:
             return
         job = pickle.loads(rd.read(struct.unpack('<Q', hdr)[0]))
         try:
-            block, x_hat, thresholds, resolution, with_normals, opt_metrics, max_deltas = job
-            normals = block[:, block.shape[1] - 3:] if with_normals else None
-            names, best = compute_optimal_thresholds(block, x_hat, thresholds, resolution, normals=normals, opt_metrics=opt_metrics,
-                                                     max_deltas=max_deltas, fixed_threshold=False)
-            out = ('ok', names, [int(b) for b in best])
+            kind, args = (job[0], job[1:]) if isinstance(job[0], str) else ('decide', job)
+            if kind == 'tally':
+                block, x_hat, thresholds, with_normals = args
+                out = ('ok',) + tuple(host_threshold_stats(block, x_hat, thresholds, normals_of(block, with_normals)))
+            else:
+                block, x_hat, thresholds, resolution, with_normals, opt_metrics, max_deltas = args
+                names, best = compute_optimal_thresholds(block, x_hat, thresholds, resolution, normals=normals_of(block, with_normals),
+                                                         opt_metrics=opt_metrics, max_deltas=max_deltas, fixed_threshold=False)
+                out = ('ok', names, [int(b) for b in best])
         except BaseException as e:   # the parent re-raises
             out = ('err', f'{type(e).__name__}: {e}', None)
         data = pickle.dumps(out, protocol=4)

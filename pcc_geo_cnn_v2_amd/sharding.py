@@ -3,16 +3,23 @@
 The reference codes the blocks of a cloud serially in one process (src/model_types.py:192-212); blocks are
 independent (no cross-block context), so here every rank (one process per GPU, torch.distributed over
 RCCL/xGMI) codes a contiguous range of the Morton-ordered block list with replicated weights.  What crosses
-ranks at the end is small and typed -- no pickled Python objects, so a C-ABI caller can reproduce it:
+ranks at the end is small and typed -- no pickled Python objects, so a C-ABI caller can reproduce it.  The shard sizes
+are a pure function of (n_blocks, world) (`shard_range`), so no size exchange is needed:
 
-  1. `all_gather_rows`: one int64 row per block (len_y, len_z, threshold indices, candidate point counts) to every rank;
-  2. `gather_bytes`: one padded uint8 `gather` of the concatenated strings to rank 0 (tens of KB per cloud), which
-     assembles the same file a single-GPU run writes;
-  3. the D1/D2 numbers of `select_best_per_opt_metric` (src/model_types.py:128-176) from per-rank partial sums
-     (`sharded_metrics`): one `all_reduce(MIN)` over the original points + one `all_reduce(SUM)` of four scalars;
-  4. only when the caller wants the reconstruction on rank 0 (`--dec_files`, `--debug`): `gather_rows` of the decoded
-     float32 points.
-Everything is latency-bound except (3)'s MIN over N_A int64 keys (8 MB per million input points).
+  encoder (compress_blocks), 4 collectives per cloud (+1 per selected candidate with --dec_files / --debug):
+  1. ONE `all_gather` of a fixed-width int64 row per block (string lengths, threshold indices, candidate point counts);
+     every rank derives every other rank's payload sizes from it;
+  2. ONE padded uint8 `gather` of the concatenated strings to rank 0 (tens of KB per cloud), which assembles the same
+     file a single-GPU run writes;
+  3. the D1/D2 numbers of `select_best_per_opt_metric` (src/model_types.py:128-176) for ALL candidates from per-rank
+     partial tallies (`utils.pc_metric.cloud_metrics_batch` with a `RankGroup`): ONE `all_reduce(MIN)` over
+     candidates x original points + ONE `all_reduce(SUM)` of candidates x 5 scalars;
+  4. only when the caller wants the reconstruction on rank 0 (`--dec_files`, `--debug`): one `gather` of the selected
+     candidate's decoded float32 points.
+  decoder (decompress_blocks), 2 collectives: one `all_gather` of the per-block point counts, one `gather` of the points.
+Everything is latency-bound except (3)'s MIN over N_A int64 keys per candidate (8 MB per million input points).
+`all_gather_rows` / `gather_rows` / `gather_bytes` without `counts` (ragged input of unknown size) prepend one small
+`all_gather` of the sizes; the codec paths always pass `counts`.
 """
 import numpy as np
 import torch
@@ -23,6 +30,10 @@ def shard_range(n_items, rank, world):
     q, r = divmod(n_items, world)
     lo = rank * q + min(rank, r)
     return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_sizes(n_items, world):
+    return [hi - lo for lo, hi in (shard_range(n_items, r, world) for r in range(world))]
 
 
 def _dist():
@@ -41,39 +52,48 @@ def _device(d, device=None):
     return torch.device('cuda', torch.cuda.current_device()) if d.get_backend() == 'nccl' else torch.device('cpu')
 
 
-def all_gather_rows(rows, device=None):
-    """rows: (n_local, k) int64/float array, k equal on all ranks.  Returns the rank-ordered concatenation on EVERY rank
-    (two collectives: row counts, then padded rows)."""
+def _row_counts(d, n_local, counts, dev):
+    """Rows held by every rank: given by the caller (no communication) or exchanged with one small all_gather."""
+    world = d.get_world_size()
+    if counts is not None:
+        counts = [int(c) for c in counts]
+        assert len(counts) == world and counts[d.get_rank()] == n_local, (counts, n_local)
+        return counts
+    cnt = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    d.all_gather(cnt, torch.tensor([n_local], dtype=torch.int64, device=dev))
+    return [int(c.item()) for c in cnt]
+
+
+def _padded(rows, cnt, dev):
+    pad = torch.zeros((max(cnt + [1]),) + tuple(rows.shape[1:]), dtype=torch.from_numpy(rows).dtype, device=dev)
+    pad[:rows.shape[0]] = torch.from_numpy(rows).to(dev)
+    return pad
+
+
+def all_gather_rows(rows, device=None, counts=None):
+    """rows: (n_local, k) array, k and dtype equal on all ranks.  Returns the rank-ordered concatenation on EVERY rank: one
+    padded `all_gather` (plus one for the row counts when `counts` -- rows per rank -- is not given)."""
     d = _dist()
     rows = np.ascontiguousarray(rows)
     if d is None:
         return rows
     world, dev = d.get_world_size(), _device(d, device)
-    t = torch.from_numpy(rows)
-    cnt = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    d.all_gather(cnt, torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev))
-    cnt = [int(c.item()) for c in cnt]
-    pad = torch.zeros((max(cnt + [1]),) + tuple(rows.shape[1:]), dtype=t.dtype, device=dev)
-    pad[:rows.shape[0]] = t.to(dev)
+    cnt = _row_counts(d, rows.shape[0], counts, dev)
+    pad = _padded(rows, cnt, dev)
     bufs = [torch.zeros_like(pad) for _ in range(world)]
     d.all_gather(bufs, pad)
     return np.concatenate([bufs[r][:cnt[r]].cpu().numpy() for r in range(world)], 0)
 
 
-def gather_rows(rows, device=None, dst=0):
-    """Like all_gather_rows, but only rank `dst` receives the concatenation (others get None): one small all_gather of the
-    row counts + one padded `gather`."""
+def gather_rows(rows, device=None, dst=0, counts=None):
+    """Like all_gather_rows, but only rank `dst` receives the concatenation (others get None): one padded `gather`."""
     d = _dist()
     rows = np.ascontiguousarray(rows)
     if d is None:
         return rows
     world, rank, dev = d.get_world_size(), d.get_rank(), _device(d, device)
-    t = torch.from_numpy(rows)
-    cnt = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    d.all_gather(cnt, torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev))
-    cnt = [int(c.item()) for c in cnt]
-    pad = torch.zeros((max(cnt + [1]),) + tuple(rows.shape[1:]), dtype=t.dtype, device=dev)
-    pad[:rows.shape[0]] = t.to(dev)
+    cnt = _row_counts(d, rows.shape[0], counts, dev)
+    pad = _padded(rows, cnt, dev)
     bufs = [torch.zeros_like(pad) for _ in range(world)] if rank == dst else None
     d.gather(pad, bufs, dst=dst)
     if rank != dst:
@@ -81,15 +101,16 @@ def gather_rows(rows, device=None, dst=0):
     return np.concatenate([bufs[r][:cnt[r]].cpu().numpy() for r in range(world)], 0)
 
 
-def gather_bytes(payload, device=None, dst=0):
-    """One byte string per rank -> list of byte strings (rank order) on rank `dst`, None elsewhere."""
+def gather_bytes(payload, device=None, dst=0, counts=None):
+    """One byte string per rank -> list of byte strings (rank order) on rank `dst`, None elsewhere.  `counts`: the payload
+    size of every rank when all ranks already know them (then this is a single `gather`)."""
     d = _dist()
     if d is None:
         return [bytes(payload)]
     world = d.get_world_size()
     arr = np.frombuffer(bytes(payload), np.uint8)
-    sizes = all_gather_rows(np.array([[arr.size]], np.int64), device)[:, 0]
-    flat = gather_rows(arr, device, dst)
+    sizes = _row_counts(d, arr.size, counts, _device(d, device))
+    flat = gather_rows(arr, device, dst, counts=sizes)
     if flat is None:
         return None
     off = np.concatenate([[0], np.cumsum(sizes)])
@@ -97,7 +118,7 @@ def gather_bytes(payload, device=None, dst=0):
 
 
 def all_reduce(arr, op, device=None):
-    """In-place-style all_reduce of a numpy array ('min' | 'sum'); returns the reduced array on every rank."""
+    """all_reduce of a numpy array ('min' | 'sum'); returns the reduced array on every rank."""
     d = _dist()
     arr = np.ascontiguousarray(arr)
     if d is None:
@@ -107,66 +128,33 @@ def all_reduce(arr, op, device=None):
     return t.cpu().numpy()
 
 
+class RankGroup:
+    """The communicator `utils.pc_metric.cloud_metrics_batch` uses under torch.distributed (the single-process one is
+    pc_metric.SingleProcess): the original cloud is replicated, every rank holds the decoded points of its own blocks.
+
+    claim(): an original point belongs to the rank that holds its nearest decoded point.  Squared distances between integer
+    points are integers, so `d2 * world + rank` is an exact int64 key and one all_reduce(MIN) yields both the global
+    minimum and its owner -- the lowest rank among equidistant candidates (a single process takes the KD-tree's pick, so D2
+    can differ from the single-process value through such cross-shard ties; D1 cannot)."""
+
+    def __init__(self, device=None):
+        self.rank, self.world = world_info()
+        self.device = device
+
+    def claim(self, sq_dist_ab, have_points):
+        n_cand = len(sq_dist_ab)
+        big = np.iinfo(np.int64).max
+        keys = np.stack([np.rint(d).astype(np.int64) * self.world + self.rank if h else np.full(len(d), big, np.int64)
+                         for d, h in zip(sq_dist_ab, have_points)]) if n_cand else np.zeros((0, 0), np.int64)
+        keys = all_reduce(keys, 'min', self.device)
+        return [None if (keys.shape[1] and keys[m, 0] == big) or not keys.shape[1] else keys[m] % self.world == self.rank
+                for m in range(n_cand)]
+
+    def total(self, tallies):
+        return all_reduce(tallies, 'sum', self.device)
+
+
 def sharded_metrics(p1, p2_local, r, p1_n=None, t1=None, device=None):
-    """utils.pc_metric.compute_metrics(p1, p2, r, p1_n) (src/utils/pc_metric.py:76-138) where the decoded cloud p2 is
-    the union of every rank's `p2_local` and the original cloud p1 (+ normals) is replicated.  Exact for D1: squared
-    distances between integer points are integers, A->B is a MIN over ranks, B->A a SUM.  For D2 the nearest decoded
-    point of an original point is taken from the lowest rank among equidistant candidates (a single process takes the
-    KD-tree's pick): sums can differ from the single-process value only through such cross-shard ties.
-    Returns None when the decoded cloud is empty on every rank (the caller substitutes -inf like model_types.py:150)."""
-    from scipy.spatial import cKDTree
-    from .utils.pc_metric import psnr, sum_d2
-    rank, world = world_info()
-    p1 = np.asarray(p1, np.float64)
-    p2 = np.asarray(p2_local, np.float64).reshape(-1, 3)
-    if t1 is None:
-        t1 = cKDTree(p1, balanced_tree=False)
-    BIG = np.iinfo(np.int64).max
-    if len(p2):
-        t2 = cKDTree(p2, balanced_tree=False)
-        _, idx2 = t2.query(p1, workers=-1 if len(p1) > 200000 else 1)
-        d2 = np.rint(np.sum((p1 - p2[idx2]) ** 2, axis=1)).astype(np.int64)
-        key = d2 * world + rank
-        _, idx1 = t1.query(p2, workers=-1 if len(p2) > 200000 else 1)
-        sum_ba = float(np.sum((p2 - p1[idx1]) ** 2))
-    else:
-        idx2 = np.zeros(len(p1), np.int64)
-        key = np.full(len(p1), BIG, np.int64)
-        idx1 = np.zeros(0, np.int64)
-        sum_ba = 0.0
-    key = all_reduce(key, 'min', device)
-    if key.size and key[0] == BIG:
-        return None
-    owner, d2min = key % world, key // world
-    mine = owner == rank
-    part = np.zeros(4, np.float64)                      # d1_sum_BA, n_B, d2_sum_AB, d2_sum_BA
-    part[0], part[1] = sum_ba, len(p2)
-    if p1_n is not None and len(p2):
-        # assign_attr (pc_metric.py:8-25) restricted to this rank's decoded points
-        counts = np.zeros(len(p2))
-        attr = np.zeros((len(p2), p1_n.shape[1]))
-        np.add.at(counts, idx2[mine], 1)
-        np.add.at(attr, idx2[mine], p1_n[mine])
-        empty = counts == 0
-        attr[empty] += p1_n[idx1[empty]]
-        counts[empty] += 1
-        p2_n = attr / counts[:, None]
-        part[2] = sum_d2(p1[mine], p2[idx2[mine]], p2_n[idx2[mine]])
-        part[3] = sum_d2(p2, p1[idx1], p1_n[idx1])
-    part = all_reduce(part, 'sum', device)
-    n1, n2 = p1.shape[0], part[1]
-    max_energy = 3 * r * r
-    s_ab, s_ba = np.float64(np.sum(d2min)), np.float64(part[0])      # numpy scalars: x / 0 -> inf like in compute_metrics
-    m_ab, m_ba = s_ab / n1, s_ba / n2
-    metrics = {
-        'd1_sum_AB': s_ab, 'd1_sum_BA': s_ba, 'd1_sum_max': max(s_ab, s_ba), 'd1_sum_mean': (s_ab + s_ba) / 2,
-        'd1_mse_AB': m_ab, 'd1_mse_BA': m_ba, 'd1_mse': max(m_ab, m_ba), 'd1_psnr_AB': psnr(m_ab, max_energy),
-        'd1_psnr_BA': psnr(m_ba, max_energy), 'd1_psnr': min(psnr(m_ab, max_energy), psnr(m_ba, max_energy))}
-    if p1_n is not None:
-        s_ab, s_ba = np.float64(part[2]), np.float64(part[3])
-        m_ab, m_ba = s_ab / n1, s_ba / n2
-        metrics.update({
-            'd2_sum_AB': s_ab, 'd2_sum_BA': s_ba, 'd2_sum_max': max(s_ab, s_ba), 'd2_sum_mean': (s_ab + s_ba) / 2,
-            'd2_mse_AB': m_ab, 'd2_mse_BA': m_ba, 'd2_mse': max(m_ab, m_ba), 'd2_psnr_AB': psnr(m_ab, max_energy),
-            'd2_psnr_BA': psnr(m_ba, max_energy), 'd2_psnr': min(psnr(m_ab, max_energy), psnr(m_ba, max_energy))})
-    return metrics
+    """compute_metrics(p1, union over ranks of p2_local, r, p1_n) on every rank (None when the union is empty)."""
+    from .utils.pc_metric import cloud_metrics_batch
+    return cloud_metrics_batch(p1, [p2_local], r, p1_n, t1, RankGroup(device))[0]

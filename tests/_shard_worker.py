@@ -63,6 +63,12 @@ def main():
     from pcc_geo_cnn_v2_amd.model_types import CompressionModel
     from pcc_geo_cnn_v2_amd.utils.octree_coding import partition_octree
     res = {}
+    calls = []
+    for name in ('all_gather', 'gather', 'all_reduce', 'broadcast', 'all_gather_object', 'gather_object'):
+        def counted(*a, _f=getattr(dist, name), _n=name, **k):
+            calls.append(_n)
+            return _f(*a, **k)
+        setattr(dist, name, counted)
     # 1. typed collectives: ragged rows to every rank, ragged bytes / rows to rank 0
     res['rows'] = sharding.all_gather_rows(np.arange((rank + 1) * 2, dtype=np.int64).reshape(rank + 1, 2) + 100 * rank)
     res['bytes'] = sharding.gather_bytes(bytes(range(rank * 3 + 1)))
@@ -74,7 +80,9 @@ def main():
     blocks, binstr = partition_octree(pts, [0, 0, 0], [64] * 3, 2)
     CompressionModel.encode_block_range = fake_encode_block_range
     model = ModelConfigType['c3p'].build()
+    del calls[:]
     data_list, metadata, _ = model.compress_blocks(None, blocks, binstr, pts, 64, 2, fixed_threshold=True)
+    res['calls_compress'] = list(calls)
     res['data_list'] = data_list
     res['metrics'] = metadata[0]['metrics']
     res['full'] = metadata[0].get('blocks_full')
@@ -84,14 +92,18 @@ def main():
     pn = np.hstack([pts, nrm / np.linalg.norm(nrm, axis=1, keepdims=True)])
     blocks_n, binstr_n = partition_octree(pn, [0, 0, 0], [64] * 3, 2)
     CompressionModel.encode_block_range = fake_encode_two_metrics
+    del calls[:]
     dl, md, _ = model.compress_blocks(None, blocks_n, binstr_n, pn, 64, 2, with_normals=True, opt_metrics=['d1_mse', 'd2_mse'],
                                       need_points=False)
+    res['calls_two'] = list(calls)
     res['two'] = dict(data_list=dl, idx=[m['idx'] for m in md], metrics=[m['metrics'] for m in md],
                       has_points=['blocks_full' in m for m in md])
     # 4. decompress_blocks: decoded points to rank 0
     CompressionModel._in_shard = False
     model.decompress_local = True
+    del calls[:]
     res['dec'] = fake_decompress(model, blocks)
+    res['calls_dec'] = list(calls)
     with open(f'{out_path}.{rank}', 'wb') as f:
         pickle.dump(res, f)
     dist.barrier()

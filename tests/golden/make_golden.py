@@ -13,6 +13,10 @@ Importable with shims (documented, no reference code is altered):
 NOT importable (TensorFlow 1.15 / tensorflow-compression 1.3 absent): model_transforms.py,
 model_types.py, focal_loss.py, patch_gaussian_conditional.py -> no vectors; the oracle for those is
 marked "parity unpinned".
+One exception (round 3): `model_types.select_best_per_opt_metric` (src/model_types.py:128-176) is plain numpy / scipy, but
+its MODULE imports tensorflow at the top.  `_tf_import_shims()` registers empty placeholder modules so that the `import`
+statements succeed; nothing of them is ever called by the function exercised (no TF behaviour is imitated, no TF-dependent
+vector is produced).
 """
 import io
 import os
@@ -47,9 +51,121 @@ def _shims():
     scipy.spatial.cKDTree = cKDTree
 
 
+class _Placeholder(types.ModuleType):
+    """Attribute sink: lets `import tensorflow...` / `tfc.GaussianConditional = patch(...)` at module import time succeed."""
+
+    def __getattr__(self, k):
+        if k.startswith('__'):
+            raise AttributeError(k)
+        m = _Placeholder(self.__name__ + '.' + k)
+        setattr(self, k, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return a[0] if a else None
+
+
+def _tf_import_shims():
+    for name in ['tensorflow', 'tensorflow.compat', 'tensorflow.compat.v1', 'tensorflow.keras', 'tensorflow.keras.layers',
+                 'tensorflow.keras.backend', 'tensorflow_core', 'tensorflow_core.python', 'tensorflow_core.python.keras',
+                 'tensorflow_core.python.keras.utils', 'tensorflow_compression', 'tensorflow_compression.python',
+                 'tensorflow_compression.python.ops']:
+        sys.modules[name] = _Placeholder(name)
+    sys.modules['tensorflow.keras.layers'].Layer = object
+
+
+def _shell_block(rng, R, n):
+    """A surface-like block: voxels of a noisy sphere shell (ties between equidistant neighbours are the rule on such grids)."""
+    c = rng.uniform(R * 0.3, R * 0.7, 3)
+    rad = rng.uniform(R * 0.2, R * 0.35)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = np.unique(np.clip(np.floor(c + d * rad + rng.normal(0, 0.3, (n, 3))), 0, R - 1), axis=0)
+    nrm = pts - c
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-9)
+    return pts, nrm
+
+
+def round3(model_opt, pc_metric, octree_coding):
+    """Round-3 fixtures (own files, own seed: the round-1 files above stay byte-identical)."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(20260929)
+    thresholds = np.linspace(0, 1.0, 2 ** 8)
+
+    # ---- threshold search WITH normals / d2_* metrics (model_opt.py:21-77 + pc_metric.py:109-131), the reference's real
+    # experiment setting (ev_experiment.yml:47: opt_metrics ['d1_mse', 'd2_mse']).  Case 2 hands the block over as float32.
+    d2 = {}
+    n_cases = 4
+    mets, deltas = ['d1_mse', 'd2_mse', 'd2_sum_max'], [np.inf, 2.0]
+    for i in range(n_cases):
+        R = 16 if i < 3 else 24
+        pts, nrm = _shell_block(rng, R, int(rng.integers(150, 500)))
+        dense = np.zeros((R, R, R), np.float32)
+        dense[tuple(pts.astype(int).T)] = 1
+        x_hat = np.clip(gaussian_filter(dense, 0.8) * 2.2 + rng.normal(0, 0.03, dense.shape), 0, 1).astype(np.float32)
+        if i == 1:      # a useless network output: the mean-point guard (model_opt.py:59-68) must fire
+            x_hat = np.clip(rng.normal(0.2, 0.2, dense.shape), 0, 1).astype(np.float32)
+        block = np.hstack([pts, nrm])
+        if i == 2:
+            block = block.astype(np.float32)
+        names, best = model_opt.compute_optimal_thresholds(block, x_hat, thresholds, 64, normals=block[:, 3:6], opt_metrics=mets,
+                                                           max_deltas=deltas, fixed_threshold=False)
+        d2[f's{i}_block'], d2[f's{i}_x_hat'] = block, x_hat
+        d2[f's{i}_names'], d2[f's{i}_best'] = np.array(names), np.array(best, np.int64)
+        # the metric dictionaries of three level sets, to pin the numbers behind the decisions
+        for t in (40, 100, 160):
+            pa = np.argwhere(x_hat > thresholds[t]).astype('float32')
+            if len(pa):
+                m = pc_metric.compute_metrics(block[:, :3], pa, 63, p1_n=block[:, 3:6])
+                d2[f's{i}_t{t}_keys'] = np.array(sorted(m))
+                d2[f's{i}_t{t}_vals'] = np.array([m[k] for k in sorted(m)], np.float64)
+    d2['n_cases'] = np.array([n_cases])
+    d2['opt_metrics'], d2['max_deltas'] = np.array(mets), np.array(deltas)
+    np.savez_compressed(os.path.join(OUT, 'model_opt_d2.npz'), **d2)
+
+    # ---- select_best_per_opt_metric (model_types.py:128-176)
+    _tf_import_shims()
+    import model_types
+    sb = {}
+    res, level = 64, 2
+    pts, nrm = _shell_block(rng, res, 4000)
+    cloud = np.hstack([pts, nrm]).astype(np.float32)                      # PLY-loaded clouds are float32
+    blocks, binstr = octree_coding.partition_octree(cloud, [0, 0, 0], [res] * 3, level)
+    names = ['d1_mse_inf', 'd2_mse_inf', 'd1_sum_mean_inf', 'd2_sum_max_inf', 'd1_mse_2.0']
+    cands = []
+    for m in range(len(names)):                                            # candidate m: every block decimated / jittered differently
+        cur = []
+        for b in blocks:
+            keep = rng.random(len(b)) < (0.95 - 0.12 * m)
+            q = b[keep, :3] + (rng.integers(-1, 2, (int(keep.sum()), 3)) if m % 2 else 0)
+            cur.append(np.unique(np.clip(q, 0, res // 2 ** level - 1), axis=0).astype(np.float32))
+        cands.append(cur)
+    for tag, wn in (('n', True), ('p', False)):
+        use_names = names if wn else [n for n in names if n.startswith('d1')]
+        use_cands = [c for n, c in zip(names, cands) if wn or n.startswith('d1')]
+        md = model_types.select_best_per_opt_metric(binstr, use_cands, level, use_names, cloud if wn else cloud[:, :3], res, wn)
+        sb[f'{tag}_names'] = np.array(use_names)
+        sb[f'{tag}_idx'] = np.array([x['idx'] for x in md], np.int64)
+        for g, x in enumerate(md):
+            sb[f'{tag}_g{g}_keys'] = np.array(sorted(x['metrics']))
+            sb[f'{tag}_g{g}_vals'] = np.array([x['metrics'][k] for k in sorted(x['metrics'])], np.float64)
+            sb[f'{tag}_g{g}_full'] = np.asarray(x['blocks_full'])
+    sb['cloud'], sb['binstr'], sb['spec'] = cloud, np.array(binstr, np.int64), np.array([res, level], np.int64)
+    sb['n_cands'] = np.array([len(cands)])
+    for m, cur in enumerate(cands):
+        sb[f'cand{m}_len'] = np.array([len(b) for b in cur], np.int64)
+        sb[f'cand{m}_cat'] = np.vstack(cur)
+    np.savez_compressed(os.path.join(OUT, 'select_best.npz'), **sb)
+    print('round-3 fixtures written')
+
+
 def main():
     sys.path.insert(0, REF)
     _shims()
+    if '--round3-only' in sys.argv:
+        import model_opt
+        from utils import octree_coding, pc_metric
+        return round3(model_opt, pc_metric, octree_coding)
     import model_syntax
     from utils import octree_coding
     import model_opt
@@ -147,6 +263,7 @@ def main():
     mo['n_cases'] = np.array([n_cases])
     np.savez_compressed(os.path.join(OUT, 'model_opt.npz'), **mo)
     print('golden fixtures written to', OUT)
+    round3(model_opt, pc_metric, octree_coding)
 
 
 if __name__ == '__main__':

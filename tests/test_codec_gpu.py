@@ -143,6 +143,50 @@ def test_adaptive_threshold_path(ctx):
         assert 0 <= t <= 255 and len(strings) == 2
 
 
+def test_adaptive_search_with_normals_dispatches_per_metric(ctx):
+    """VERDICT r02 item 5 / the reference's real experiment (ev_experiment.yml:47: opt_metrics ['d1_mse', 'd2_mse'] with
+    normals): d1_* decisions come from the GPU distance transforms even though normals are present, the host pool receives
+    'tally' jobs only (KD-tree neighbour lists for the D2 columns), and every decision equals the in-process host search
+    (model_opt.compute_optimal_thresholds, itself pinned by the reference-generated tests/golden/model_opt_d2.npz).  With
+    d1 metrics only and normals in the input no host job is issued at all."""
+    from pcc_geo_cnn_v2_amd import model_opt
+    from pcc_geo_cnn_v2_amd.utils.octree_coding import partition_octree
+    res = 32
+    rng = np.random.default_rng(11)
+    blocks8 = make_blocks(3, res, seed=9)
+    pts = np.vstack([b + np.array([(i & 1), (i >> 1) & 1, (i >> 2) & 1]) * res for i, b in enumerate(blocks8)])
+    nrm = rng.normal(size=pts.shape)
+    cloud = np.hstack([pts, nrm / np.linalg.norm(nrm, axis=1, keepdims=True)])
+    blocks, binstr = partition_octree(cloud, [0, 0, 0], [2 * res] * 3, 1)
+    m = ModelConfigType['c3p'].build(batch_size=2)
+    m.compress([1, 1, res, res, res])
+    m.set_weights(scaled_weights(m, 2.2))
+    mets, deltas = ['d1_mse', 'd2_mse'], [np.inf, 2.0]
+    strings, thr, cand, names, dbg = m.encode_block_range(ctx, blocks, 2 * res, with_normals=True, opt_metrics=mets, max_deltas=deltas,
+                                                          debug=True)
+    assert names == ['d1_mse_inf', 'd2_mse_inf', 'd1_mse_2.0', 'd2_mse_2.0']
+    assert m.last_host_job_kind == 'tally' and m.host_search_jobs == len(blocks)
+    for j, blk in enumerate(blocks):
+        xh = np.clip(dbg[j]['x_hat'][0, ..., 0], 0, 1)
+        hn, hb = model_opt.compute_optimal_thresholds(blk, xh, m.thresholds, 2 * res, normals=blk[:, 3:6], opt_metrics=mets, max_deltas=deltas)
+        assert hn == names and hb == thr[j], (j, hb, thr[j])
+        for k, t in enumerate(thr[j]):
+            assert np.array_equal(cand[j][k], np.argwhere(xh > np.float32(m.thresholds[t])).astype(np.float32))
+    assert len({tuple(t) for t in thr}) > 0 and any(t != 255 for tt in thr for t in tt)
+    # whole-cloud selection on top: one winner per group
+    data_list, metadata, _ = m.compress_blocks(ctx, blocks, binstr, cloud, 2 * res, 1, with_normals=True, opt_metrics=mets, max_deltas=deltas)
+    assert len(metadata) == 2 and names[metadata[0]['idx']].startswith('d1') and names[metadata[1]['idx']].startswith('d2')
+    assert 'd2_psnr' in metadata[1]['metrics'] and len(data_list) == 2
+    # d1 only, normals present: everything on the GPU
+    before = m.host_search_jobs
+    _, thr1, _, names1, _ = m.encode_block_range(ctx, blocks, 2 * res, with_normals=True, opt_metrics=['d1_mse'], max_deltas=deltas)
+    assert m.host_search_jobs == before and names1 == ['d1_mse_inf', 'd1_mse_2.0']
+    assert [t[0] for t in thr1] == [t[0] for t in thr] and [t[1] for t in thr1] == [t[2] for t in thr]
+    # d2 only: nothing for the GPU search to do -> complete decisions from the host pool
+    _, thr2, _, names2, _ = m.encode_block_range(ctx, blocks, 2 * res, with_normals=True, opt_metrics=['d2_mse'], max_deltas=[np.inf])
+    assert m.last_host_job_kind == 'decide' and [t[0] for t in thr2] == [t[1] for t in thr]
+
+
 def test_blocks_128_cubed_roundtrip_and_layer_parity(ctx, oracle):
     """BASELINE.json configs[4] shape (c3p graph, 128^3 blocks) on the fp32 path: the nets are fully convolutional
     (x_shape // 8, // 16 at model_types.py:305,403).  Size-independent checks: enc -> dec bit-identical, decoded point

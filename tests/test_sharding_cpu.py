@@ -70,6 +70,12 @@ def test_two_rank_sharded_compress_equals_single_process(tmp_path):
                     assert ma[k] == v, k
                 else:   # D2 depends on which of several equidistant neighbours is taken (cross-shard ties: lowest rank)
                     assert np.isclose(ma[k], v, rtol=0.05), (k, ma[k], v)
+    # the number of collectives DESIGN.md §6 states: no size exchanges (shard sizes are a function of (n_blocks, world))
+    for r in range(2):
+        assert two[r]['calls_compress'] == ['all_gather', 'gather', 'all_reduce', 'all_reduce', 'gather']   # last: --dec_files points
+        assert two[r]['calls_two'] == ['all_gather', 'gather', 'all_reduce', 'all_reduce']                 # 2 candidates, need_points=False
+        assert two[r]['calls_dec'] == ['all_gather', 'gather']
+    assert one[0]['calls_compress'] == one[0]['calls_two'] == one[0]['calls_dec'] == []
     # decoder: all points on rank 0, in block order
     assert two[1]['dec'] is None and len(two[0]['dec']) == one[0]['n_blocks']
     for a, b in zip(two[0]['dec'], one[0]['dec']):
