@@ -61,7 +61,7 @@ constexpr int PLANE_BYTES = CHUNKS * 1024;             // 21504: three planes en
 constexpr int U_BASE = 3 * PLANE_BYTES;
 constexpr int U_BYTES = 48 * 1024;                     // 3 z taps x 16 points x 64 lanes x float4
 constexpr int LDS_BYTES = U_BASE + U_BYTES;            // 113664
-constexpr int LDS_BYTES_MULTI = U_BASE + 2 * U_BYTES;  // 162816 <= 160 KB: U double-buffered across the cin groups of one launch
+constexpr int LDS_BYTES_CIN = U_BASE + 2 * U_BYTES;    // 162816 <= 160 KB (conv16_wino_cin_kernel): tile ring + two U buffers
 constexpr int ITEMS = 6;                               // chunks per wave: wave w stages chunks 5w .. 5w+5 (5, 10, 15 twice: same data)
 
 struct WinoArgs {
@@ -76,7 +76,7 @@ struct WinoArgs {
     int flags, ocs, oco;
     int ics, ico;       // input channel stride / offset of this launch's 16-channel cin group
     int rcs;            // residual channel stride (its channel offset follows the cout group)
-    int ncig;           // MULTI: cin groups processed by one launch (u: [cin group][cout group][48][64][4])
+    int ncig;           // cin groups processed by one launch of conv16_wino_cin_kernel (u: [cin group][cout group][48][64][4])
 };
 
 // Measured on MI355X (tools/ubench/mfma_valu.hip): a wave's VALU instructions do NOT overlap with its own fp32 MFMAs
@@ -126,16 +126,10 @@ __device__ __forceinline__ void transform_y_row(f32x4 (&V)[16], const f32x4 (&P)
     }
 }
 
-// MULTI: all cin groups of a Cin = Cout = 16 g layer in ONE launch.  A workgroup marches over its z slab once per cin group,
-// one after the other, as one continuous sequence of steps: the plane ring, the accumulator rotation and the U prefetch run
-// across the group boundary (the last two steps of a group prefetch the first two planes of the next one; the next group's U
-// arrives global -> LDS into the second U buffer during the march), the partial sums of the earlier groups are read back from
-// `out` (same lane, same address as its own earlier store), bias / ReLU / residual are applied in the last group only.  Same
-// arithmetic and summation order as one launch per group (PRE), without the launch boundaries, the per-launch U load and
-// the pipeline refill.
-template <bool RELU, bool CLIP, bool PRE, bool MULTI = false>
+// PRE: this launch handles a later cin group of a multi-group layer launched group by group (clip layers; PCC_WINO_PER_GROUP):
+// the partial sums of the earlier groups are read back from `out` (same lane, same address as its own earlier store).
+template <bool RELU, bool CLIP, bool PRE>
 __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg) {
-    static_assert(!MULTI || (!PRE && !CLIP), "MULTI covers the whole layer; clip layers take the per-group launches");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = lane & 15, g = lane >> 4;
@@ -200,7 +194,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             const int v = 36 * TY + 18 * dy + 9 * (dx & 1) + TX + (dx >> 1);
             ra[dy * 4 + dx] = (unsigned)(v * 64 + ((g ^ ((v >> 1) & 3)) << 4));
         }
-    unsigned ua = (unsigned)(U_BASE + lane * 16);          // (MULTI: toggles between the two U buffers per cin group)
+    const unsigned ua = (unsigned)(U_BASE + lane * 16);
 
     // ---- epilogue addressing: lane writes couts 4g..4g+3 of the 2x2 voxels of its tile
     const int ox0 = X0 + 2 * TX, oy0 = Y0 + 2 * TY;
@@ -217,12 +211,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     float* out_n = a.out + (size_t)n * a.D * HW * a.ocs;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bias_l = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + 16 * cog + g * 4) : zero4;
-    // MULTI: per-group state (wave-uniform).  The bias enters in the LAST group, like in the per-group launches.
-    int cig = 0, sl = 0;                                   // current cin group, step inside its march
-    bool fin = !MULTI || a.ncig == 1;
-    f32x4 bias4 = fin ? bias_l : zero4;
-    const f32x4 ninf4 = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    f32x4 relu4 = fin ? zero4 : ninf4;                     // lower clamp of the epilogue: 0 in the last group of a ReLU layer
+    const f32x4 bias4 = bias_l;
 
     // ---- prologue: input planes s = 0, 1 (z = zb-1, zb) -> ring slots 0, 1
     stage_plane(0, zb - 1);
@@ -249,22 +238,16 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;     // plane zo of step s = 0
     unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
     // one input plane: s = step index (input plane z = zb-1+s), PH = s mod 3
-    auto step = [&](auto ph_tag, int s_arg) __attribute__((always_inline)) {
+    auto step = [&](auto ph_tag, int s) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
-        const int s = MULTI ? sl : s_arg;
         constexpr unsigned slotN = (unsigned)((PH + 1) % 3) * PLANE_BYTES;   // plane s+1 (read)
         constexpr unsigned slotW = (unsigned)((PH + 2) % 3) * PLANE_BYTES;   // plane s+2 (written)
         constexpr int AF = PH;                                               // acc slot of the plane finished by dz = 2
         const bool zo_ok = s >= 2;                                           // the finished plane zo = zb - 2 + s exists
         // plane-sized descriptors of the finished output plane; zero-sized (loads return 0, stores are dropped) while s < 2
-        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res && fin ? HWR : 0u);
-        // MULTI: the partial sums of the earlier groups (zero-sized for the first group: loads return 0)
-        const __amdgpu_buffer_rsrc_t rpre = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), MULTI && zo_ok && cig > 0 ? HWO : 0u);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res ? HWR : 0u);
         const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok ? HWO : 0u);
         res_pl += HWR; out_pl += HWO;
-        const bool last_of_group = MULTI && s == nsteps - 1;
-        constexpr unsigned UTOG = (unsigned)(U_BASE ^ (U_BASE + U_BYTES));      // the two U bases differ in bits above lane * 16
-        const unsigned ua_next = last_of_group ? (ua ^ UTOG) : ua;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int dz = 2 - (j >> 2), py = j & 3;
@@ -273,7 +256,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             {
                 const int jn = (j + 1) % 12, dzn = 2 - (jn >> 2), pyn = jn & 3;
 #pragma unroll
-                for (int px = 0; px < 4; ++px) Ub[(j + 1) & 1][px] = ldsr((j == 11 ? ua_next : ua) + (unsigned)(((dzn * 4 + pyn) * 4 + px) * 1024));
+                for (int px = 0; px < 4; ++px) Ub[(j + 1) & 1][px] = ldsr(ua + (unsigned)(((dzn * 4 + pyn) * 4 + px) * 1024));
             }
             // (2) the 16 MFMAs of this row: 4 independent accumulators, k-chained; dz = 0 opens a new output plane
 #pragma unroll
@@ -293,24 +276,12 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             //     the next plane are written in slots 9, 10, 11 and (row 3) slot 0 of the next step: no register copies.
             if (j == 0) transform_y_row(Vc, Vn, 3);
             else if (j == 1) {
-                if constexpr (!MULTI) {
-                    const bool ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
-                    const __amdgpu_buffer_rsrc_t rp = make_rsrc((const void*)(ok ? in_pl : (unsigned long long)in_n), ok ? HWI : 0u);
-                    in_pl += HWI;
+                const bool ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
+                const __amdgpu_buffer_rsrc_t rp = make_rsrc((const void*)(ok ? in_pl : (unsigned long long)in_n), ok ? HWI : 0u);
+                in_pl += HWI;
 #pragma unroll
-                    for (int it = 0; it < ITEMS; ++it)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + slotW + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
-                } else {
-                    // plane two steps ahead in the continuous sequence: inside this group, or plane 0 / 1 of the next group
-                    const bool wrap = s + 2 >= nsteps;
-                    const int zl = wrap ? s + 2 - nsteps : s + 2;              // step index inside its group
-                    const int z = zb - 1 + zl, cg = wrap ? cig + 1 : cig;
-                    const bool ok = (unsigned)z < (unsigned)a.D && cg < a.ncig;
-                    const __amdgpu_buffer_rsrc_t rp = make_rsrc(ok ? in_n + (size_t)z * HW * a.ics + 16 * cg : in_n, ok ? HWI - (unsigned)(64 * cg) : 0u);
-#pragma unroll
-                    for (int it = 0; it < ITEMS; ++it)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + slotW + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
-                }
+                for (int it = 0; it < ITEMS; ++it)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + slotW + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i] + slotN);
             } else if (j == 2) transform_x_rows(Vn, 0, 2);
@@ -323,7 +294,6 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
                 for (int q = 2 * (j - 4); q < 2 * (j - 4) + 2; ++q) {
                     resv[q] = buf_load4(rres, rvo[q], 0);
                     if (PRE) prev[q] = buf_load4(rout, ovo[q], 0);
-                    if (MULTI) prev[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpre, (int)ovo[q], 0, 1));   // glc: this lane's own earlier store, past the L1
                 }
             }
             if (j >= 5 && j <= 8) {
@@ -342,9 +312,9 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
                 for (int q = 2 * (j - 8); q < 2 * (j - 8) + 2; ++q) {
                     f32x4 o = S[q >> 1][q & 1];
-                    if (PRE || MULTI) o = add4(o, prev[q]);
+                    if (PRE) o = add4(o, prev[q]);
                     // one v_maximum3_f32 per element: fmaxf on the result of the inline-asm packed add costs a second v_max (NaN quieting)
-                    if (RELU) o = __builtin_elementwise_maximum(o, MULTI ? relu4 : zero4);
+                    if (RELU) o = __builtin_elementwise_maximum(o, zero4);
                     o = add4(o, resv[q]);     // zeros without PCC_CONV_ADD (zero-sized buffer)
                     if (CLIP) {
 #pragma unroll
@@ -366,43 +336,306 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             if (j == 9) transform_y_row(Vc, Vn, 0);
             else if (j == 10) transform_y_row(Vc, Vn, 1);
             else if (j == 11) transform_y_row(Vc, Vn, 2);
-            if (MULTI && (j == 10 || j == 11)) {
-                // U of the next group -> the other U buffer, 48 chunks of 1 KB: 12 per wave, one in each of these two VALU-light
-                // slots over the first six steps of the march (they are older than the last 12 memory ops of the NEXT step, whose
-                // closing vmcnt wait therefore covers them: complete by the end of step 6 <= nsteps - 2)
-                if (s < 6 && cig + 1 < a.ncig) {
-                    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u + ((size_t)(cig + 1) * a.nco + cog) * (U_BYTES / 4), (unsigned)U_BYTES);
-                    const unsigned ub = (ua ^ UTOG) - (unsigned)(lane * 16);       // base of the other buffer
-                    const int chunk = wave * 12 + 2 * s + (j - 10);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr)(smem + ub + chunk * 1024), 16, (int)(lane * 16), chunk * 1024, 0, 0);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // The LDS-direct loads of plane s+2 (slot 1) must have landed before the barrier publishes them to the other
         // waves; the compiler only orders them against this wave's own LDS reads.  vmcnt counts in issue order: the 4
-        // residual (+4 partial-sum) loads of slots 4 / 5, the 4 stores of slots 8 / 9 (and MULTI's two U pieces of slots
-        // 10 / 11) were issued later and may stay in flight.
-        __builtin_amdgcn_s_waitcnt(MULTI ? 0x0F7E : PRE ? 0x0F7C : 0x0F78);      // vmcnt(14 / 12 / 8) expcnt(7) lgkmcnt(15)
+        // residual (+4 partial-sum) loads of slots 4 / 5 and the 4 stores of slots 8 / 9 were issued later and may stay in flight.
+        __builtin_amdgcn_s_waitcnt(PRE ? 0x0F7C : 0x0F78);      // vmcnt(12 / 8) expcnt(7) lgkmcnt(15)
         __syncthreads();     // plane s+2 is published; nobody still reads plane s+1
-        if constexpr (MULTI) {
-            if (++sl == nsteps) {       // (wave-uniform) next cin group: same slab, same outputs
-                sl = 0; ++cig;
-                fin = cig == a.ncig - 1;
-                bias4 = fin ? bias_l : zero4;
-                relu4 = fin ? zero4 : ninf4;
-                ua ^= UTOG;
-                res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;
-                out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
-            }
-        }
     };
 
-    const int total = MULTI ? nsteps * a.ncig : nsteps;
+    const int total = nsteps;
     for (int s = 0; s < total; s += 3) {
         step(std::integral_constant<int, 0>{}, s);
         if (s + 1 < total) step(std::integral_constant<int, 1>{}, s + 1);
         if (s + 2 < total) step(std::integral_constant<int, 2>{}, s + 2);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Cin = Cout = 16 G, G in {2, 4}: the cin groups INSIDE the z march (round 3).
+//
+// conv16_wino_kernel handles one 16-channel cin group per march; a G-group layer then needs G marches whose partial sums
+// travel through `out` (written, re-read and re-written: 32 -> 32 @32^3 ran at 0.60-0.63 of the MFMA peak, 64 -> 64 @16^3 at
+// 0.53, against 0.68-0.74 for the one-group layer).  Here the accumulators of the three output planes in flight (192
+// AccVGPRs, one cout group) stay live across the cin groups: the march is a linear sequence of MICRO-STEPS m = (input
+// plane s, cin group c), c fastest.  Micro-step m multiplies V(tile m) with U[c]; meanwhile tile m+1 is read from LDS and
+// transformed, tile m+2 arrives global -> LDS.  Only the LAST cin group of a plane reduces / stores the finished output
+// plane (A^T . A, bias, ReLU, residual); the other G-1 micro-steps carry the input transform as their only VALU work.
+// No partial sum ever leaves the registers, one launch per layer, no read-modify-write of `out`.
+//
+// LDS (162816 B): ring of 3 tiles (18 x 18 x 16 ch; a tile is dead once its patches are in registers, so the ring is
+// indexed by m, not by (s, c)) + two U buffers of 48 KB.  G = 2: both cin groups' U stay resident (the second one streams in
+// during micro-step 0).  G = 4: U[c(m+1)] streams global(L2) -> LDS into the idle buffer during micro-step m, 12 pieces of
+// 1 KB per wave spread over slots 0..7 (48 KB per ~7k cycles and CU = 7 B/cycle, an eighth of the L2 rate).
+// The tile ring phase (m mod 3) is independent of the accumulator phase (s mod 3, compile time): the 16 patch addresses
+// advance by a wave-uniform delta per micro-step (16 v_add_u32) instead of being immediates.
+//
+// Summation order: per output element cin group 0's taps, then group 1's, ... in ONE fp32 accumulator chain, then A^T . A.
+// (The per-group path reduces every group's accumulator separately and adds the reduced values: same tolerance against the
+// oracle, not the same bits.)  Fixed order, independent of launch geometry: bit-deterministic.
+template <bool RELU, int G>
+__global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int nwg) {
+    static_assert(G == 2 || G == 4, "the two U buffers alternate with the cin group: G must be even");
+    constexpr bool STREAM = G > 2;           // G = 2: both U resident from the prologue on; G = 4: U[c(m+1)] streams during m
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = lane & 15, g = lane >> 4;
+    auto ldsr = [&](unsigned off) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + off); };
+
+    int wg = xcd_remap(blockIdx.x, nwg);
+    const int cog = wg % a.nco; wg /= a.nco;
+    const int tx_ = wg % a.ntx; wg /= a.ntx;
+    const int ty_ = wg % a.nty; wg /= a.nty;
+    const int zs = wg % a.zsplit;
+    const int n = wg / a.zsplit;
+    const int X0 = tx_ * 16, Y0 = ty_ * 16, zb = zs * a.zlen;
+    const int nsteps = a.zlen + 2;
+    const size_t HW = (size_t)a.H * a.W;
+    const unsigned HWI = (unsigned)(HW * a.ics * 4), HWR = (unsigned)(HW * a.rcs * 4), HWO = (unsigned)(HW * a.ocs * 4);
+    const float* in_n = a.in + (size_t)n * a.D * HW * a.ics;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    // ---- tile staging (global -> LDS directly; swizzle and x de-interleave on the global side, see conv16_wino_kernel)
+    unsigned rel[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int slot = (wave * 5 + it) * 64 + lane;
+        const int v = slot >> 2, c4 = (slot & 3) ^ ((v >> 1) & 3);
+        const int yrow = v / 18, r = v - yrow * 18, par = r >= 9 ? 1 : 0, col = r - 9 * par, xi = 2 * col + par;
+        const int y = Y0 - 1 + yrow, x = X0 - 1 + xi;
+        const bool ok = v < PLANE_VOX && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        rel[it] = ok ? (unsigned)(((y * a.W + x) * a.ics + c4 * 4) * 4) : kOOB;
+    }
+    // tile of micro-step (sp, cg): input plane z = zb - 1 + sp, channels 16 cg .. 16 cg + 15; `addr` = address of that
+    // plane's channel 16 cg (kept incrementally by the caller: no 64-bit multiply in the loop)
+    auto stage_tile = [&](unsigned ring_off, int sp, int cg, unsigned long long addr) __attribute__((always_inline)) {
+        const bool ok = (unsigned)(zb - 1 + sp) < (unsigned)a.D && sp < nsteps;
+        const __amdgpu_buffer_rsrc_t rp = make_rsrc((const void*)(ok ? addr : (unsigned long long)in_n), ok ? HWI - (unsigned)(64 * cg) : 0u);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + ring_off + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
+    };
+    // one 1 KB piece of U[cg] (this cout group) -> U buffer at `ubase`; piece index k = 0 .. 11 of this wave
+    auto stage_u = [&](unsigned ubase, int cg, int k) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u + ((size_t)cg * a.nco + cog) * (U_BYTES / 4), (unsigned)U_BYTES);
+        const int chunk = wave * 12 + k;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr)(smem + ubase + chunk * 1024), 16, (int)(lane * 16), chunk * 1024, 0, 0);
+    };
+
+    // ---- per-lane patch read addresses (ring slot 0), tile of this lane
+    const int wx = wave & 1, wy = wave >> 1;
+    const int TX = 4 * wx + (t & 3), TY = 4 * wy + (t >> 2);
+    unsigned ra[16];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int v = 36 * TY + 18 * dy + 9 * (dx & 1) + TX + (dx >> 1);
+            ra[dy * 4 + dx] = (unsigned)(v * 64 + ((g ^ ((v >> 1) & 3)) << 4));
+        }
+    constexpr unsigned UTOG = (unsigned)(U_BASE ^ (U_BASE + U_BYTES));
+    unsigned ua = (unsigned)(U_BASE + lane * 16);          // toggles between the two U buffers every micro-step
+
+    // ---- epilogue addressing
+    const int ox0 = X0 + 2 * TX, oy0 = Y0 + 2 * TY;
+    unsigned ovo[4], rvo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned vox = (unsigned)((oy0 + (q >> 1)) * a.W + ox0 + (q & 1));
+        ovo[q] = (vox * (unsigned)a.ocs + (unsigned)a.oco + 16u * cog + 4u * g) * 4u;
+        rvo[q] = (vox * (unsigned)a.rcs + 16u * cog + 4u * g) * 4u;
+    }
+    const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
+    const float* res_n = has_res ? a.res + (size_t)n * a.D * HW * a.rcs : a.in;
+    float* out_n = a.out + (size_t)n * a.D * HW * a.ocs;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias_l = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + 16 * cog + g * 4) : zero4;
+
+    // ---- prologue: tiles 0, 1 -> ring slots 0, 1; U[0] -> buffer 0 (G = 2: and U[1] -> buffer 1)
+    unsigned long long tile_pl = (unsigned long long)in_n + (unsigned long long)(long long)(zb - 1) * HWI;    // tile (plane 0, group 0)
+    stage_tile(0, 0, 0, tile_pl);
+    stage_tile(PLANE_BYTES, 0, 1, tile_pl + 64);
+    tile_pl += 128;                                                                                          // tile m = 2
+    if (G == 2) tile_pl += HWI - 128;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) stage_u((unsigned)U_BASE, 0, k);
+    if (!STREAM) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) stage_u((unsigned)(U_BASE + U_BYTES), 1, k);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    __syncthreads();
+
+    f32x4 Vc[16], Vn[16], Ub[4], acc[3][16], S[2][2], resv[4], ost[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i]);
+    transform_x_rows(Vn, 0, 4);
+    transform_y_row(Vc, Vn, 0);
+    transform_y_row(Vc, Vn, 1);
+    transform_y_row(Vc, Vn, 2);
+#pragma unroll
+    for (int px = 0; px < 4; ++px) Ub[px] = ldsr(ua + (unsigned)((2 * 16 + px) * 1024));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ra[i] += (unsigned)PLANE_BYTES;      // -> the slot of tile 1
+
+    // wave-uniform march state
+    int c = 0, s = 0;                        // cin group and input plane of the current micro-step m
+    int s2 = 2 / G, c2 = 2 % G;              // plane / cin group of tile m + 2 (its address: tile_pl)
+    unsigned wr_off = 2u * PLANE_BYTES;      // ring slot of tile m + 2
+    int rd_slot = 1;                         // ring slot of tile m + 1 (what ra[] points into)
+    unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;     // plane zo of plane s = 0
+    unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
+
+    // one micro-step.  PH = s mod 3 (accumulator rotation), FIRST / FIN = first / last cin group of the plane: all compile
+    // time -- wave-uniform run-time branches around the slot pieces were measured at ~1000 cycles per micro-step (12 % of it:
+    // every taken branch restarts the instruction fetch), more than the epilogue they skip.
+    auto step = [&](auto ph_tag, auto first_tag, auto fin_tag) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr int AF = PH;
+        constexpr bool first = decltype(first_tag)::value, fin = decltype(fin_tag)::value;
+        const bool zo_ok = s >= 2;
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res && fin ? HWR : 0u);
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok && fin ? HWO : 0u);
+        const int cn = c + 1 == G ? 0 : c + 1;                        // cin group of micro-step m + 1
+        // STREAM: U[cn] -> the idle buffer during this micro-step (after the last micro-step: a harmless extra copy of U[0]);
+        // its first row can only be read after the closing barrier.  Otherwise it is resident and prefetched across the barrier.
+        const unsigned ub_next = (ua ^ UTOG) - (unsigned)(lane * 16);
+        const int rd_delta = rd_slot == 2 ? -2 * PLANE_BYTES : PLANE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int dz = 2 - (j >> 2), py = j & 3;
+            const int as = (PH + 2 - dz) % 3;
+            // (1) + (2) the 16 MFMAs of this row in two halves of two points (px) each, k-chained and alternating between the two
+            //     points (a dependent MFMA is two issue slots away: no stall on the 40-cycle latency).  The U fragments of a half
+            //     are dead after its 8 MFMAs: the SAME registers receive the fragments of the next row right behind them, so every
+            //     LDS read has >= 8 MFMAs (256 cycles) of cover in every micro-step -- most micro-steps have no VALU block behind the
+            //     MFMAs of slots 4..8 that could cover it (in the one-group kernel every slot has one) -- at 16 registers for U.
+            //     The dz = 0 rows open a new output plane in the FIRST cin group (from 0; point (1,1) enters all four outputs
+            //     with weight +1 and carries the bias) and continue it in the others.
+            const int jn = j + 1, dzn = 2 - (jn >> 2), pyn = jn & 3;
+            const unsigned urow = j < 11 ? ua + (unsigned)((dzn * 4 + pyn) * 4 * 1024) : (ua ^ UTOG) + (unsigned)(2 * 16 * 1024);
+            const bool INIT = first && dz == 0;      // (folds: first is a constant, dz follows from the unrolled j)
+            auto half = [&](auto h_tag) __attribute__((always_inline)) {
+                constexpr int PX0 = decltype(h_tag)::value * 2;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int px = PX0; px < PX0 + 2; ++px) {
+                        const f32x4 cc = (INIT && kk == 0) ? ((py == 1 && px == 1) ? bias_l : zero4) : acc[as][py * 4 + px];
+                        acc[as][py * 4 + px] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ub[px][kk], Vc[py * 4 + px][kk], cc, 0, 0, 0);
+                    }
+            };
+            auto next_u = [&](int px0) __attribute__((always_inline)) {
+                if (j < 11 || !STREAM) {
+                    Ub[px0] = ldsr(urow + (unsigned)(px0 * 1024));
+                    Ub[px0 + 1] = ldsr(urow + (unsigned)((px0 + 1) * 1024));
+                }
+            };
+            half(std::integral_constant<int, 0>{});
+            next_u(0);
+            half(std::integral_constant<int, 1>{});
+            next_u(2);
+            if (j < 11 || !STREAM) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (3) everything else, as one block behind the MFMAs of the slot
+            if (j == 0) transform_y_row(Vc, Vn, 3);
+            else if (j == 1) {
+                stage_tile(wr_off, s2, c2, tile_pl);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i]);
+            } else if (j == 2) transform_x_rows(Vn, 0, 2);
+            else if (j == 3) transform_x_rows(Vn, 2, 4);
+            if (STREAM) {        // U[cn] -> the idle buffer: pieces 0..11 of this wave in slots 0, 2..7
+                if (j == 0) { stage_u(ub_next, cn, 0); stage_u(ub_next, cn, 1); }
+                else if (j >= 2 && j <= 5) { stage_u(ub_next, cn, 2 * j - 2); stage_u(ub_next, cn, 2 * j - 1); }
+                else if (j == 6 || j == 7) stage_u(ub_next, cn, j + 4);
+            }
+            if (fin) {
+                if (j == 4 || j == 5) {
+#pragma unroll
+                    for (int q = 2 * (j - 4); q < 2 * (j - 4) + 2; ++q) resv[q] = buf_load4(rres, rvo[q], 0);
+                }
+                if (j >= 5 && j <= 8) {
+                    const int r = j - 5;
+                    const f32x4 m0 = acc_read(acc[AF][r * 4 + 0]), m1 = acc_read(acc[AF][r * 4 + 1]), m2 = acc_read(acc[AF][r * 4 + 2]), m3 = acc_read(acc[AF][r * 4 + 3]);
+                    const f32x4 r0 = add4(add4(m0, m1), m2), r1 = sub4(sub4(m1, m2), m3);
+                    if (r == 0) { S[0][0] = r0; S[0][1] = r1; }
+                    else if (r == 1) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = r0; S[1][1] = r1; }
+                    else if (r == 2) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
+                    else { S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
+                }
+                if (j == 8 || j == 9) {
+#pragma unroll
+                    for (int q = 2 * (j - 8); q < 2 * (j - 8) + 2; ++q) {
+                        f32x4 o = S[q >> 1][q & 1];
+                        if (RELU) o = __builtin_elementwise_maximum(o, zero4);
+                        ost[q] = add4(o, resv[q]);     // zeros without PCC_CONV_ADD (zero-sized buffer)
+                    }
+#pragma unroll
+                    for (int q = 2 * (j - 8); q < 2 * (j - 8) + 2; ++q) buf_store4(rout, ost[q], ovo[q], 0);
+                }
+                if (j == 9 || j == 10) {      // store data registers stay unwritten for one more slot (see conv16_wino_kernel)
+#pragma unroll
+                    for (int q = 2 * (j - 9); q < 2 * (j - 9) + 2; ++q) asm volatile("" ::"v"(ost[q]));
+                }
+            }
+            if (j == 9) transform_y_row(Vc, Vn, 0);
+            else if (j == 10) {
+                transform_y_row(Vc, Vn, 1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ra[i] += (unsigned)rd_delta;
+            } else if (j == 11) {
+                transform_y_row(Vc, Vn, 2);
+#pragma unroll
+                for (int i = 8; i < 16; ++i) ra[i] += (unsigned)rd_delta;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // tile m+2 (slot 1) and the U pieces (slots 0..7) must have landed before the barrier publishes them; the only younger
+        // memory operations are the four stores of a final micro-step
+        if (fin) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        __syncthreads();
+        // ---- advance (all wave-uniform)
+        ua ^= UTOG;
+        // opaque: for G = 2 the toggle is periodic in the loop body and the optimiser would otherwise hoist all 96 row addresses
+        // (base + offset beyond the 16-bit DS immediate) out of the loop into spilled registers
+        asm volatile("" : "+v"(ua));
+        if (STREAM) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) Ub[px] = ldsr(ua + (unsigned)((2 * 16 + px) * 1024));
+        }
+        rd_slot = rd_slot == 2 ? 0 : rd_slot + 1;
+        wr_off = wr_off == 2u * PLANE_BYTES ? 0u : wr_off + (unsigned)PLANE_BYTES;
+        tile_pl += 64;
+        if (++c2 == G) { c2 = 0; ++s2; tile_pl += HWI - 64 * G; }
+        if (++c == G) { c = 0; ++s; res_pl += HWR; out_pl += HWO; }
+    };
+
+    // one input plane = G micro-steps: first, (G - 2 middle ones: one body, looped), last
+    auto plane = [&](auto ph_tag) __attribute__((always_inline)) {
+        step(ph_tag, std::true_type{}, std::false_type{});
+        if (G > 2) {
+#pragma nounroll
+            for (int k = 0; k < G - 2; ++k) step(ph_tag, std::false_type{}, std::false_type{});
+        }
+        step(ph_tag, std::false_type{}, std::true_type{});
+    };
+#pragma nounroll
+    for (int sp = 0; sp < nsteps; sp += 3) {
+        plane(std::integral_constant<int, 0>{});
+        if (sp + 1 < nsteps) plane(std::integral_constant<int, 1>{});
+        if (sp + 2 < nsteps) plane(std::integral_constant<int, 2>{});
     }
 }
 
@@ -445,16 +678,18 @@ int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const f
                                     conv16_wino_kernel<false, true, false>,  conv16_wino_kernel<true, true, false>,
                                     conv16_wino_kernel<false, false, true>,  conv16_wino_kernel<true, false, true>,
                                     conv16_wino_kernel<false, true, true>,   conv16_wino_kernel<true, true, true>};
-    // all cin groups of a 64-channel layer in one launch (MULTI) unless the layer clips, its slabs are too short for the U
-    // prefetch schedule, or PCC_WINO_PER_GROUP asks for the per-group launches (bit-identical results: tests compare the two).
-    // Measured: 64 -> 64 @16^3 x32 173 -> 167 us (launch boundaries); 32 -> 32 @32^3 (two groups) gains nothing and stays per group.
+    // multi-group layers take conv16_wino_cin_kernel unless they clip or PCC_WINO_PER_GROUP asks for one launch per cin group
+    // (A/B runs; a test compares the two within the tolerance).  Measured (round 3, batch 32): 32 -> 32 @32^3 276 -> 251 us,
+    // 64 -> 64 @16^3 172 -> 159 us.
     const bool per_group = getenv("PCC_WINO_PER_GROUP") != nullptr;       // (read per call: a test flips it)
-    if (G >= 4 && !(d->flags & PCC_CONV_CLIP01) && a.zlen >= 6 && !per_group) {
-        static const kern_t mk[2] = {conv16_wino_kernel<false, false, false, true>, conv16_wino_kernel<true, false, false, true>};
+    // G = 2, 4: the cin groups inside the march, accumulators live across them (conv16_wino_cin_kernel), one launch
+    if ((G == 2 || G == 4) && !(d->flags & PCC_CONV_CLIP01) && !per_group) {
+        static const kern_t ck[4] = {conv16_wino_cin_kernel<false, 2>, conv16_wino_cin_kernel<true, 2>,
+                                     conv16_wino_cin_kernel<false, 4>, conv16_wino_cin_kernel<true, 4>};
         a.u = u_packed; a.ico = 0; a.ncig = G; a.flags = d->flags;
-        const kern_t mkern = mk[(d->flags & PCC_CONV_RELU) ? 1 : 0];
-        { const int rc = pcc_enable_big_lds((const void*)mkern, LDS_BYTES_MULTI); if (rc != PCC_OK) return rc; }
-        hipLaunchKernelGGL(mkern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES_MULTI, st, a, nwg);
+        const kern_t ckern = ck[(G == 4 ? 2 : 0) + ((d->flags & PCC_CONV_RELU) ? 1 : 0)];
+        { const int rc = pcc_enable_big_lds((const void*)ckern, LDS_BYTES_CIN); if (rc != PCC_OK) return rc; }
+        hipLaunchKernelGGL(ckern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES_CIN, st, a, nwg);
         PCC_CHECK_HIP(hipGetLastError());
         return PCC_OK;
     }
