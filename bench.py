@@ -36,6 +36,57 @@ PEAK_FP32_MFMA = 157.3       # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16
 GAIN_ANALYSIS, GAIN_SYNTHESIS, FINAL_BIAS, EB_INIT_SCALE = 1.35, 1.8, 0.0, 0.2
 
 
+def c3p_step_flops(res, batch, num_cu=256, winograd=True):
+    """(algorithmic, executed) fp32 MFMA flops of ONE block through compress graph + decompress graph of c3p (the unit of
+    SURVEY.md 8d): algorithmic = direct convolution, 2 * MACs as the reference executes them; executed = what the kernels
+    issue: the k3 stride-1 layers that csrc/conv_wino.hip takes (conv_mfma.hip dispatch rule: Cin = Cout in {16, 32, 64}, H and W
+    multiples of 16, 32-channel layers only from 32^3 up) run 16 instead of 36 multiplies per 2x2 outputs and z tap and march
+    zlen + 2 input planes per zlen outputs (zlen = D / z-split, the split that gives every CU a workgroup)."""
+    def wino_factor(ch, d):
+        if not winograd or d % 16 or (ch == 32 and d < 32):
+            return 1.0
+        zs, base = 1, batch * (d // 16) ** 2 * (ch // 16)
+        while base * zs < num_cu and d % (zs * 2) == 0 and d // (zs * 2) >= 8:
+            zs *= 2
+        zlen = d // zs
+        return 16.0 / 36.0 * (zlen + 2) / zlen
+    alg = ex = 0.0
+
+    def conv(cin, cout, k, d_out_or_in, wino=False):       # MACs counted on the grid the taps are applied on
+        nonlocal alg, ex
+        f = 2.0 * d_out_or_in ** 3 * k ** 3 * cin * cout
+        alg += f
+        ex += f * (wino_factor(cin, d_out_or_in) if wino else 1.0)
+
+    def analysis():
+        d = res
+        for f_in, f in ((1, 16), (16, 32), (32, 64)):
+            d //= 2
+            conv(f_in, f, 3, d)                               # stride-2 conv: taps per output voxel
+            conv(f, f, 3, d, True); conv(f, f, 3, d, True)
+        conv(64, 64, 3, d, True)
+
+    def synthesis():
+        d = res // 8
+        for f_in, f in ((64, 64), (64, 32), (32, 16)):
+            conv(f_in, f, 3, d)                               # stride-2 transposed conv: 27 taps per INPUT voxel
+            d *= 2
+            conv(f, f, 3, d, True); conv(f, f, 3, d, True)
+        conv(16, 1, 3, d)
+
+    def hyper_a():
+        d = res // 8
+        conv(64, 64, 3, d, True); conv(64, 64, 3, d // 2); conv(64, 64, 3, d // 2, True)
+
+    def hyper_s():
+        d = res // 16
+        conv(64, 64, 3, d, True); conv(64, 64, 3, d); conv(64, 64, 3, 2 * d, True)
+
+    analysis(); hyper_a(); hyper_s(); synthesis()             # compress graph (model_types.py:379-388)
+    hyper_s(); synthesis()                                    # decompress graph (:403-408)
+    return alg, ex
+
+
 def synthetic_weights(model, seed=42):
     from pcc_geo_cnn_v2_amd.entropy_models import EntropyBottleneck
     w = {k: v for k, v in model.get_weights().items() if not k.startswith('entropy_bottleneck/')}
@@ -156,6 +207,7 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs[4] (128^3, batch 8, fp16) measurement that the default run appends')
     ap.add_argument('--chunk', type=int, default=CHUNK)
     ap.add_argument('--coder-threads', type=int, default=0,
                     help='host range-coder threads of this rank (default: logical cores / ranks); for studying the host share')
@@ -207,13 +259,25 @@ def main():
     x = synthetic_blocks(BATCH, device, seed0=rank * BATCH)
     chunks = [x[i:i + args.chunk].contiguous() for i in range(0, BATCH, args.chunk)]
 
-    def run(steps):
+    stamps = []          # host time at which the results of every chunk became available (steady-state window below)
+
+    def run(steps, mdl=None, chs=None):
         n_pts, n_bytes, n_blocks = 0, 0, 0
-        for strings, cnt_e, pts in model.roundtrip_stream(ctx, (c for _ in range(steps) for c in chunks)):
+        del stamps[:]
+        for strings, cnt_e, pts in (mdl or model).roundtrip_stream(ctx, (c for _ in range(steps) for c in (chs or chunks))):
+            stamps.append(time.perf_counter())
             n_blocks += len(strings)
             n_bytes += sum(len(s) for ss in strings for s in ss)
             n_pts += sum(len(p) for p in pts)
         return n_blocks, n_bytes, n_pts
+
+    def steady_ms_per_step(chunks_per_step):
+        """ms per step inside a window that starts after the 3-deep pipeline has filled and ends before it drains: the
+        results of chunk k arrive while chunks k+1, k+2 are in flight, so the spacing of arrivals is the step time."""
+        K = len(stamps)
+        if K < 8:
+            return None
+        return 1e3 * (stamps[K - 3] - stamps[2]) / (K - 5) * chunks_per_step
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -235,19 +299,74 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    steady_ms = steady_ms_per_step(BATCH // args.chunk)
     kern_ms = ops.profile_read(ctx)
     ops.profile_select(ctx, -1, -1)
     assert len(kern_ms) == 2 * args.steps * (BATCH // args.chunk), f'{len(kern_ms)} timed launches of the dominant layer'
+    multi = None
     if dist is not None:
+        # what the driver cannot see from outside: that RCCL really spans `world` ranks on distinct devices, what each rank
+        # did, and what the closing collectives cost
+        own = torch.tensor([elapsed, n_blocks, float(steady_ms or 0.0)], dtype=torch.float64, device=device)
+        torch.cuda.synchronize(device)
+        tc0 = time.perf_counter()
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         stats = torch.tensor([n_blocks, n_bytes, n_pts], dtype=torch.float64, device=device)
         dist.all_reduce(stats)  # the one collective of the sharded path: totals to rank 0
         tot_blocks = int(stats[0].item())
+        torch.cuda.synchronize(device)
+        coll_ms = 1e3 * (time.perf_counter() - tc0)
+        per_rank = [torch.zeros_like(own) for _ in range(dist.get_world_size())]
+        dist.all_gather(per_rank, own)
+        uuid = str(getattr(torch.cuda.get_device_properties(device), 'uuid', f'cuda:{local_rank}'))
+        uuids = [None] * dist.get_world_size()
+        dist.all_gather_object(uuids, uuid)
+        multi = {'rccl_world_size': dist.get_world_size(), 'backend': dist.get_backend(), 'device_uuids': uuids,
+                 'distinct_devices': len(set(uuids)),
+                 'per_rank_blocks_per_s': [float(r[1] / r[0]) for r in per_rank],
+                 'per_rank_elapsed_s': [float(r[0]) for r in per_rank],
+                 'per_rank_steady_ms_per_step': [float(r[2]) or None for r in per_rank],
+                 'final_collectives_ms': coll_ms,
+                 'final_collectives': 'all_reduce(MAX) of the elapsed time + all_reduce(SUM) of (blocks, bytes, points); after the timed region'}
     else:
         tot_blocks = n_blocks
     assert n_blocks == args.steps * BATCH
+
+    # BASELINE.json configs[4] (c6 = the c3p graph, 128^3 blocks, batch 8, fp16 MFMA) measured in the SAME process, so that the
+    # driver's one `bench.py --gpus 1` run times it too.  A separate, labelled object: never the headline value.
+    secondary = None
+    if args.workload == 'configs1' and args.precision == 'fp32' and world == 1 and not args.no_secondary:
+        res2, batch2, steps2 = 128, 8, max(6, args.steps // 2)
+        m2 = ModelConfigType['c3p'].build(batch_size=batch2, coder_threads=coder_threads, precision='fp16')
+        m2.compress([1, 1, res2, res2, res2])
+        m2.set_weights(w)
+        g = torch.Generator(device='cpu').manual_seed(99)
+        x2 = (torch.rand((batch2, res2, res2, res2), generator=g) < 0.02).float().to(device)     # Bernoulli(0.02) occupancy (SURVEY.md 8d variant)
+        ch2 = [x2]
+        run(2, m2, ch2)
+        ops.profile_select(ctx, L.PCC_NET_SYNTHESIS_PROGRESSIVE_V2, DOM_LAYER)
+        torch.cuda.synchronize(device)
+        s0 = time.perf_counter()
+        nb2, nby2, npt2 = run(steps2, m2, ch2)
+        torch.cuda.synchronize(device)
+        el2 = time.perf_counter() - s0
+        k2 = ops.profile_read(ctx)
+        ops.profile_select(ctx, -1, -1)
+        avg2 = float(np.mean(k2)) if k2 else float('nan')
+        bytes2 = 3.0 * batch2 * res2 ** 3 * 16 * 2
+        secondary = {'metric': 'voxel_blocks_128cubed_per_sec_encode_decode_FP16_MODE', 'value': nb2 / el2, 'unit': '128^3 blocks/s',
+                     'equivalent_64cubed_blocks_per_s': 8 * nb2 / el2, 'steps': steps2, 'warmup': 2, 'ms_per_step': 1e3 * el2 / steps2,
+                     'steady_ms_per_step': steady_ms_per_step(1),
+                     'dtype': 'f16 operands and mid-network storage / f32 accumulate', 'data': 'synthetic',
+                     'config': {'workload': 'BASELINE.json configs[4]: deepest config (paper c6 = the c3p graph), batch=8 synthetic 128^3 occupancy grids, '
+                                            'fp16 MFMA with fp16 mid-network storage, fixed threshold idx 128, encode+decode',
+                                'bytes_per_block': nby2 / nb2, 'decoded_points_per_block': npt2 / nb2},
+                     'roofline': {'bound': 'hbm', 'kernel': 'conv_f16_kernel<16>: Conv3DTranspose 16->16 k3 s1 + fp16 residual @128^3 x8 (synthesis layer 8)',
+                                  'achieved': bytes2 / (avg2 * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': bytes2 / (avg2 * 1e-3) / 1e9 / 8000.0,
+                                  'traffic': None, 'algorithmic_bytes_per_launch': bytes2, 'avg_launch_ms': avg2, 'launches_timed': len(k2)}}
+        del m2, x2
 
     if rank == 0:
         value = tot_blocks / elapsed
@@ -267,6 +386,8 @@ def main():
             dom_kernel = 'conv16_pers_kernel<2,4,2,20,2> (Conv3DTranspose 16->16 k3 s1 @64^3, 4 launches per step)'
             dom_note = 'direct implicit-GEMM kernel (PCC_NO_WINOGRAD=1): executed == algorithmic flops'
         achieved_exec = exec_flops / (avg_ms * 1e-3) / 1e12
+        alg_step, exec_step = c3p_step_flops(RES, args.chunk, winograd=winograd)
+        assert abs(alg_step / FLOPS_PER_BLOCK - 1) < 2e-3, (alg_step, FLOPS_PER_BLOCK)       # the layer walk reproduces SURVEY.md 8d
         alg_bytes16 = 3.0 * args.chunk * RES ** 3 * 16 * 2            # fp16 mode: in + residual + out of the timed layer, fp16
         traffic, traffic_src = None, None
         prof = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
@@ -285,8 +406,16 @@ def main():
                        'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'coder_threads_per_rank': coder_threads, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
                        'bytes_per_block': n_bytes / n_blocks, 'decoded_points_per_block': n_pts / n_blocks,
-                       'conv_tflops_whole_step': value * FLOPS_PER_BLOCK / 1e12,
-                       'conv_frac_of_fp32_mfma_peak_whole_step': value * FLOPS_PER_BLOCK / 1e12 / (PEAK_FP32_MFMA * world)},
+                       'conv_tflops_whole_step_algorithmic': value * FLOPS_PER_BLOCK / 1e12,
+                       # direct-convolution flops / time / peak: the Winograd layers execute 2.1-2.2x fewer multiplies
+                       # than that, so this figure MAY EXCEED 1; the executed fraction next to it cannot
+                       'conv_frac_of_fp32_mfma_peak_whole_step_algorithmic_winograd_may_exceed_1': value * FLOPS_PER_BLOCK / 1e12 / (PEAK_FP32_MFMA * world),
+                       'conv_frac_of_fp32_mfma_peak_whole_step_executed': (value * exec_step / 1e12 / (PEAK_FP32_MFMA * world)) if args.precision == 'fp32' else None,
+                       'executed_flops_per_block': exec_step if args.precision == 'fp32' else None,
+                       'steady_state_ms_per_step': steady_ms,
+                       'steady_state_blocks_per_s_per_gpu': (1e3 * BATCH / steady_ms) if steady_ms else None,
+                       'steady_state_note': 'window from the arrival of chunk 2 to the arrival of chunk K-3 (3-deep pipeline filled, not draining); '
+                                            '`value` / `ms_per_step` above include fill and drain'},
             'roofline': ({'bound': 'hbm', 'kernel': 'conv_f16_kernel<16> (fp16 storage, v_mfma_f32_16x16x32_f16): Conv3DTranspose 16->16 k3 s1 + fp16 residual, synthesis layer 8',
                           'achieved': alg_bytes16 / (avg_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg_bytes16 / (avg_ms * 1e-3) / 1e9 / 8000.0,
                           'traffic': None, 'algorithmic_bytes_per_launch': alg_bytes16, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms),
@@ -300,6 +429,8 @@ def main():
                          'algorithmic_speedup_vs_direct_roof': achieved / PEAK_FP32_MFMA,
                          'note': dom_note}),
         }
+        out['secondary'] = secondary
+        out['multi_gpu'] = multi
         if world == 1 and not args.no_cpu_baseline and args.workload == 'configs1':
             out['cpu_baseline'] = cpu_baseline(model, w, x[:4].cpu().numpy())
         else:

@@ -94,12 +94,34 @@ class _Pinned:
 
     def __init__(self):
         self._b = {}
+        self._rings = {}
 
     def get(self, tag, shape, dtype):
         key = (tag, tuple(shape), dtype)
         if key not in self._b:
             self._b[key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
         return self._b[key]
+
+    def ring(self, tag, shape, dtype, depth=4):
+        """Next buffer of a ring of `depth` pinned buffers (the decoder's staging buffers: a chunk's buffer is still the source
+        of an asynchronous host->device copy while the host already fills the next chunk's).  Returns (buffer, release):
+        call release(stream) after enqueuing the last device operation that reads the buffer; the ring waits for that event
+        before it hands the buffer out again -- no pinned allocation (a device-synchronising call) in the steady state."""
+        key = (tag, tuple(shape), dtype)
+        r = self._rings.setdefault(key, {'next': 0, 'buf': [None] * depth, 'busy': [None] * depth})
+        i = r['next']
+        r['next'] = (i + 1) % depth
+        if r['busy'][i] is not None:
+            r['busy'][i].synchronize()
+            r['busy'][i] = None
+        if r['buf'][i] is None:
+            r['buf'][i] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+
+        def release(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            r['busy'][i] = ev
+        return r['buf'][i], release
 
 
 class CompressionModel:
@@ -678,16 +700,17 @@ class CompressionModelV1(CompressionModel):
         B = len(strings)
         eb = self.entropy_bottleneck
         yshape = self._stream_shape(B, [v // 8 for v in dhw], self.num_filters)
-        ysym_h = torch.empty(yshape, dtype=torch.int32, pin_memory=True)
+        ysym_h, ysym_release = self._pinned.ring('dec_ysym', yshape, torch.int32)
         n = int(np.prod(yshape[1:]))
         rows, mod = self._eb_rows(n, self.num_filters)
         ops.range_decode_batch(eb.table, [s[0] for s in strings], [n] * B, None if rows is None else [rows] * B, mod,
                                self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
-        return dict(ysym_h=ysym_h)
+        return dict(ysym_h=ysym_h, ysym_release=ysym_release)
 
     def _decode_phase_b(self, ctx, st, dhw, debug, thr=None):
         eb = self.entropy_bottleneck
         ysym = self._from_stream_order(st['ysym_h'].to(ctx.device, non_blocking=True))
+        st['ysym_release'](torch.cuda.current_stream(ctx.device))
         codec = self._codec(ctx)
         if codec is not None:                      # dequantise -> synthesis (-> threshold + compaction) in one ABI call
             t = ops.codec_decode_main(ctx, codec, ysym, dhw, thr)
@@ -819,12 +842,14 @@ class CompressionModelV2(CompressionModel):
         B, F = len(strings), self.num_filters
         eb, gc = self.entropy_bottleneck, self.conditional_bottleneck
         zshape = self._stream_shape(B, [v // 16 for v in dhw], F)
-        zsym_h = torch.empty(zshape, dtype=torch.int32, pin_memory=True)
+        # per-slot cached pinned buffers (like the encoder's): nothing is allocated in the steady state
+        zsym_h, zsym_release = self._pinned.ring('dec_zsym', zshape, torch.int32)
         nz = int(np.prod(zshape[1:]))
         rows, mod = self._eb_rows(nz, F)
         ops.range_decode_batch(eb.table, [s[1] for s in strings], [nz] * B, None if rows is None else [rows] * B, mod,
                                self.coder_threads, out=[zsym_h[b].numpy() for b in range(B)])
         zsym = self._from_stream_order(zsym_h.to(ctx.device, non_blocking=True))
+        zsym_release(torch.cuda.current_stream(ctx.device))
         codec = self._codec(ctx)
         if codec is not None:                      # dequantise z -> hyper-synthesis -> indexes in one ABI call
             t = ops.codec_decode_hyper(ctx, codec, zsym, dhw)
@@ -834,7 +859,8 @@ class CompressionModelV2(CompressionModel):
             sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
             idx = ops.scale_to_index(ctx, sigma, self._dev(ctx, 'scale_table', gc.scale_table_f32))
         idx_s = self._to_stream_order(idx)
-        idx_h = torch.empty(idx_s.shape, dtype=torch.int32, pin_memory=True)
+        # (the host reads idx_h synchronously in phase b, long before the ring comes round: no release event needed)
+        idx_h, _ = self._pinned.ring('dec_idx', idx_s.shape, torch.int32)
         idx_h.copy_(idx_s, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(ctx.device))
@@ -846,11 +872,12 @@ class CompressionModelV2(CompressionModel):
         strings, idx_h = st['strings'], st['idx_h']
         B = len(strings)
         st['ev'].synchronize()
-        ysym_h = torch.empty(idx_h.shape, dtype=torch.int32, pin_memory=True)
+        ysym_h, ysym_release = self._pinned.ring('dec_ysym', idx_h.shape, torch.int32)
         n = int(np.prod(idx_h.shape[1:]))
         ops.range_decode_batch(gc.table, [s[0] for s in strings], [n] * B, [idx_h[b] for b in range(B)], 0,
                                self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
         ysym = self._from_stream_order(ysym_h.to(ctx.device, non_blocking=True))
+        ysym_release(torch.cuda.current_stream(ctx.device))
         codec = self._codec(ctx)
         if codec is not None:                      # dequantise -> synthesis (-> threshold + compaction) in one ABI call
             t = ops.codec_decode_main(ctx, codec, ysym, dhw, thr)
