@@ -58,6 +58,11 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 bool pcc_wino_eligible(const pcc_conv_desc* d);
 int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed,
                   const float* bias, const float* residual, float* out, hipStream_t st);
+// z-marching k3 stride-2 transposed conv for 32 -> 16 / 64 -> 32 (conv_tr2m.hip); weights in conv_tr2g_kernel's packed order
+bool pcc_tr2m_eligible(const pcc_conv_desc* d);
+bool pcc_tr2m_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d);
+int pcc_conv_tr2m(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_tr2g, const float* bias, float* out,
+                  hipStream_t st);
 // fp16-storage k3 stride-1 kernel for Cin = Cout in {16, 32} (conv_f16.hip), PCC_CONV_IN16 layers
 bool pcc_f16_eligible(const pcc_conv_desc* d);
 size_t pcc_f16_packed_bytes(int C);

@@ -161,6 +161,58 @@ def test_winograd_concat_offset(ctx, oracle):
     assert np.all(got[..., :12] == 0) and np.all(got[..., 28:] == 0)
 
 
+TR2M_CASES = [
+    # N, D, H, W, cin, cout, bias, relu   (H, W multiples of 16: conv_tr2m.hip; D = 1, odd D, z-split slabs, several x-y tiles)
+    (1, 1, 16, 16, 32, 16, True, True), (2, 5, 16, 32, 32, 16, True, False), (1, 9, 32, 16, 64, 32, False, True),
+    (3, 8, 16, 16, 64, 32, True, True), (1, 16, 48, 32, 32, 16, True, True), (2, 32, 16, 16, 32, 16, False, False),
+    (1, 4, 32, 32, 64, 32, True, True),
+]
+
+
+@pytest.mark.parametrize('case', TR2M_CASES)
+def test_marching_stride2_transposed_conv_matches_oracle(ctx, oracle, monkeypatch, case):
+    """conv_tr2m.hip (round 3): Conv3DTranspose k3 stride 2 (/root/reference/src/model_transforms.py:78) marching along z with
+    the accumulators of three output planes live -- against the C oracle (TF SAME crop 0 low / 1 high); bit-deterministic and
+    independent of batch / z split; within the tolerance of the tiled conv_tr2g_kernel (same taps, another summation order)."""
+    N, D, H, W, cin, cout, bias, relu = case
+    monkeypatch.setenv('PCC_TR2M', '1')                     # also where AUTO would prefer the tiled kernel (64 -> 32 on short slabs)
+    got = _run(ctx, oracle, N, D, H, W, cin, cout, 3, 2, True, bias, relu, False, L.PCC_IMPL_MFMA, seed=41)
+    rng = np.random.default_rng(41)
+    x = torch.from_numpy(rng.standard_normal((N, D, H, W, cin)).astype(np.float32)).to(ctx.device)
+    w = (rng.standard_normal((3, 3, 3, cout, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    layer = ops.ConvLayer(w, rng.standard_normal(cout).astype(np.float32) if bias else None, 2, True, relu)
+    a = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
+    a2 = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
+    one = ops.conv3d(ctx, x[N - 1:].contiguous(), layer, impl=L.PCC_IMPL_MFMA)       # other grid / z split
+    monkeypatch.delenv('PCC_TR2M')
+    monkeypatch.setenv('PCC_NO_TR2M', '1')
+    b = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
+    torch.cuda.synchronize()
+    assert got.shape == (N, 2 * D, 2 * H, 2 * W, cout)
+    assert torch.equal(a, a2) and torch.equal(a[N - 1:], one)
+    assert not torch.equal(a, b) or D * H * W <= 256, 'PCC_TR2M did not select the marching kernel'
+    assert (a - b).abs().max().item() <= 2e-5 * (1 + b.abs().max().item())
+
+
+def test_marching_stride2_concat_offset_and_real_geometry(ctx):
+    """channel-offset output (ocs / oco) and the bench's launch: 32 -> 16 @32^3 -> 64^3 x 32 blocks (256 workgroups, two 16-plane
+    slabs per column) against the generic reference-order kernel."""
+    rng = np.random.default_rng(8)
+    w = (rng.standard_normal((3, 3, 3, 16, 32)) / np.sqrt(27 * 32)).astype(np.float32)
+    layer = ops.ConvLayer(w, rng.standard_normal(16).astype(np.float32), 2, True, True)
+    x = torch.randn((1, 3, 16, 16, 32), generator=torch.Generator().manual_seed(1)).to(ctx.device)
+    out = torch.zeros((1, 6, 32, 32, 24), device=ctx.device)
+    ops.conv3d(ctx, x, layer, out=out, out_coffset=4)
+    ref = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_GENERIC)
+    assert (out[..., 4:20] - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+    assert torch.all(out[..., :4] == 0) and torch.all(out[..., 20:] == 0)
+    x = torch.randn((32, 32, 32, 32, 32), generator=torch.Generator().manual_seed(2)).to(ctx.device)
+    a = ops.conv3d(ctx, x, layer)
+    for n0 in (0, 13, 31):
+        ref = ops.conv3d(ctx, x[n0:n0 + 1].contiguous(), layer, impl=L.PCC_IMPL_GENERIC)
+        assert (a[n0:n0 + 1] - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+
+
 # stated tolerance of the fp16-MFMA mode (BASELINE.json configs[4]): operands rounded to fp16 (2^-11 relative), fp32
 # accumulation over <= 27*64 products -> |err| <= 4e-3 * (1 + max|ref|) against the double-accumulation oracle
 TOL_F16 = 4e-3
