@@ -41,7 +41,8 @@ def c3p_step_flops(res, batch, num_cu=256, winograd=True):
     SURVEY.md 8d): algorithmic = direct convolution, 2 * MACs as the reference executes them; executed = what the kernels
     issue: the k3 stride-1 layers that csrc/conv_wino.hip takes (conv_mfma.hip dispatch rule: Cin = Cout in {16, 32, 64}, H and W
     multiples of 16, 32-channel layers only from 32^3 up) run 16 instead of 36 multiplies per 2x2 outputs and z tap and march
-    zlen + 2 input planes per zlen outputs (zlen = D / z-split, the split that gives every CU a workgroup)."""
+    zlen + 2 input planes per zlen outputs, the first of them with a third of its MFMA rows (zlen = D / z-split, the split that
+    gives every CU a workgroup)."""
     def wino_factor(ch, d):
         if not winograd or d % 16 or (ch == 32 and d < 32):
             return 1.0
@@ -49,7 +50,7 @@ def c3p_step_flops(res, batch, num_cu=256, winograd=True):
         while base * zs < num_cu and d % (zs * 2) == 0 and d // (zs * 2) >= 8:
             zs *= 2
         zlen = d // zs
-        return 16.0 / 36.0 * (zlen + 2) / zlen
+        return 16.0 / 36.0 * (zlen + 1 + 1.0 / 3.0) / zlen      # + a full tail plane + the dz-0 rows of the head plane
     alg = ex = 0.0
 
     def conv(cin, cout, k, d_out_or_in, wino=False):       # MACs counted on the grid the taps are applied on
@@ -375,10 +376,10 @@ def main():
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
         winograd = os.environ.get('PCC_NO_WINOGRAD') is None
         if winograd:
-            # conv_wino.hip: F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap), RES+2 input planes per RES outputs
-            exec_flops = flops_launch * 16.0 / 36.0 * (RES + 2) / RES
+            # conv_wino.hip: F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap), RES+2 input planes per RES outputs (the first one runs its dz = 0 rows only)
+            exec_flops = flops_launch * 16.0 / 36.0 * (RES + 1 + 1.0 / 3.0) / RES
             dom_kernel = 'conv16_wino_kernel<relu> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the decoder; layer 7 runs the same kernel: 4 launches per step)'
-            dom_note = ('achieved/frac = fp32 MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3) in x-y + direct z: 16/36 * 66/64 of '
+            dom_note = ('achieved/frac = fp32 MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3) in x-y + direct z: 16/36 * 65.33/64 of '
                         'the direct-convolution flops) / HIP-event launch time / dense fp32 MFMA peak; algorithmic_* restate it in the '
                         'direct-convolution flops of SURVEY.md 8d (what a direct kernel would have to sustain for the same time)')
         else:

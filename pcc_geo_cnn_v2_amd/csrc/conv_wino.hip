@@ -231,15 +231,19 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     transform_y_row(Vc, Vn, 1);
     transform_y_row(Vc, Vn, 2);          // row 3 follows in slot 0 of the first step
 #pragma unroll
-    for (int px = 0; px < 4; ++px) Ub[0][px] = ldsr(ua + (unsigned)((2 * 16 + px) * 1024));   // first row: dz = 2, py = 0
+    for (int px = 0; px < 4; ++px) Ub[0][px] = ldsr(ua + (unsigned)(px * 1024));   // first step: dz = 0 rows only; its first row (dz 0, py 0) is slot 8 -> buffer 0
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }   // (planes finishing at s < 2 are never stored)
 
     unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;     // plane zo of step s = 0
     unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
     // one input plane: s = step index (input plane z = zb-1+s), PH = s mod 3
-    auto step = [&](auto ph_tag, int s) __attribute__((always_inline)) {
+    // DZ0: the slab's first input plane (zb - 1) only feeds output plane zb, through its dz = 0 rows -- 4 of the 12 MFMA rows
+    // (66 -> 65.33 plane-equivalents per 64-plane slab, 18 -> 17.33 per 16-plane slab); see conv16_wino_cin_kernel for why the last
+    // plane stays a full one
+    auto step = [&](auto ph_tag, int s, auto dz0_tag) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
+        constexpr bool DZ0 = decltype(dz0_tag)::value;
         constexpr unsigned slotN = (unsigned)((PH + 1) % 3) * PLANE_BYTES;   // plane s+1 (read)
         constexpr unsigned slotW = (unsigned)((PH + 2) % 3) * PLANE_BYTES;   // plane s+2 (written)
         constexpr int AF = PH;                                               // acc slot of the plane finished by dz = 2
@@ -253,14 +257,14 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             const int dz = 2 - (j >> 2), py = j & 3;
             const int as = (PH + 2 - dz) % 3;
             // (1) U fragments of the next row (wraps to the first row of the next step)
-            {
+            if (!DZ0 || dz == 0) {
                 const int jn = (j + 1) % 12, dzn = 2 - (jn >> 2), pyn = jn & 3;
 #pragma unroll
                 for (int px = 0; px < 4; ++px) Ub[(j + 1) & 1][px] = ldsr(ua + (unsigned)(((dzn * 4 + pyn) * 4 + px) * 1024));
             }
             // (2) the 16 MFMAs of this row: 4 independent accumulators, k-chained; dz = 0 opens a new output plane
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < (!DZ0 || dz == 0 ? 4 : 0); ++kk)
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {
                     // a new output plane starts from 0, except point (1,1) which enters all four outputs with weight +1
@@ -345,11 +349,11 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
         __syncthreads();     // plane s+2 is published; nobody still reads plane s+1
     };
 
-    const int total = nsteps;
-    for (int s = 0; s < total; s += 3) {
-        step(std::integral_constant<int, 0>{}, s);
-        if (s + 1 < total) step(std::integral_constant<int, 1>{}, s + 1);
-        if (s + 2 < total) step(std::integral_constant<int, 2>{}, s + 2);
+    step(std::integral_constant<int, 0>{}, 0, std::true_type{});
+    for (int s = 1; s < nsteps; s += 3) {
+        step(std::integral_constant<int, 1>{}, s, std::false_type{});
+        if (s + 1 < nsteps) step(std::integral_constant<int, 2>{}, s + 1, std::false_type{});
+        if (s + 2 < nsteps) step(std::integral_constant<int, 0>{}, s + 2, std::false_type{});
     }
 }
 
@@ -477,7 +481,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     transform_y_row(Vc, Vn, 1);
     transform_y_row(Vc, Vn, 2);
 #pragma unroll
-    for (int px = 0; px < 4; ++px) Ub[px] = ldsr(ua + (unsigned)((2 * 16 + px) * 1024));
+    for (int px = 0; px < 4; ++px) Ub[px] = ldsr(ua + (unsigned)(px * 1024));      // first plane: dz = 0 rows only, first row (dz 0, py 0)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }
 #pragma unroll
@@ -494,10 +498,18 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     // one micro-step.  PH = s mod 3 (accumulator rotation), FIRST / FIN = first / last cin group of the plane: all compile
     // time -- wave-uniform run-time branches around the slot pieces were measured at ~1000 cycles per micro-step (12 % of it:
     // every taken branch restarts the instruction fetch), more than the epilogue they skip.
-    auto step = [&](auto ph_tag, auto first_tag, auto fin_tag) __attribute__((always_inline)) {
+    // DZ0: the slab's first input plane (zb - 1) only feeds output plane zb, through its dz = 0 rows: that plane runs 4 of the 12
+    // MFMA rows (the rest of the step -- staging, input transform -- is unchanged): 10 -> 9.33 plane-equivalents per 8-plane slab
+    // (64 -> 64 @16^3), 34 -> 33.33 (32 -> 32 @32^3).  The mirror image for the last plane (dz = 2 rows only) was built too: as
+    // compile-time bodies its extra control flow around 192 live accumulator registers made the allocator spill (90 - 780
+    // registers, whatever the loop shape), as a run-time row mask the 12 scalar branches per micro-step cost the 32-channel layer
+    // more (+7 % wave cycles) than the plane saves.
+    auto step = [&](auto ph_tag, auto first_tag, auto fin_tag, auto dz0_tag) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr int AF = PH;
         constexpr bool first = decltype(first_tag)::value, fin = decltype(fin_tag)::value;
+        constexpr bool DZ0 = decltype(dz0_tag)::value;
+        constexpr int J_FIRST_NEXT = (DZ0 && !fin) ? 8 : 0;      // first active row of the NEXT micro-step (the plane after the dz-0-only plane is a full one)
         const bool zo_ok = s >= 2;
         const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res && fin ? HWR : 0u);
         const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok && fin ? HWO : 0u);
@@ -517,8 +529,9 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
             //     MFMAs of slots 4..8 that could cover it (in the one-group kernel every slot has one) -- at 16 registers for U.
             //     The dz = 0 rows open a new output plane in the FIRST cin group (from 0; point (1,1) enters all four outputs
             //     with weight +1 and carries the bias) and continue it in the others.
-            const int jn = j + 1, dzn = 2 - (jn >> 2), pyn = jn & 3;
-            const unsigned urow = j < 11 ? ua + (unsigned)((dzn * 4 + pyn) * 4 * 1024) : (ua ^ UTOG) + (unsigned)(2 * 16 * 1024);
+            const bool active = !DZ0 || dz == 0;
+            const int jn = j == 11 ? J_FIRST_NEXT : j + 1, dzn = 2 - (jn >> 2), pyn = jn & 3;
+            const unsigned urow = (j == 11 ? (ua ^ UTOG) : ua) + (unsigned)((dzn * 4 + pyn) * 4 * 1024);
             const bool INIT = first && dz == 0;      // (folds: first is a constant, dz follows from the unrolled j)
             auto half = [&](auto h_tag) __attribute__((always_inline)) {
                 constexpr int PX0 = decltype(h_tag)::value * 2;
@@ -536,15 +549,17 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
                     Ub[px0 + 1] = ldsr(urow + (unsigned)((px0 + 1) * 1024));
                 }
             };
-            half(std::integral_constant<int, 0>{});
-            next_u(0);
-            half(std::integral_constant<int, 1>{});
-            next_u(2);
-            if (j < 11 || !STREAM) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (active) {
+                half(std::integral_constant<int, 0>{});
+                next_u(0);
+                half(std::integral_constant<int, 1>{});
+                next_u(2);
+                if (j < 11 || !STREAM) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // (3) everything else, as one block behind the MFMAs of the slot
@@ -612,8 +627,9 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
         // (base + offset beyond the 16-bit DS immediate) out of the loop into spilled registers
         asm volatile("" : "+v"(ua));
         if (STREAM) {
+            constexpr int dzf = 2 - (J_FIRST_NEXT >> 2);
 #pragma unroll
-            for (int px = 0; px < 4; ++px) Ub[px] = ldsr(ua + (unsigned)((2 * 16 + px) * 1024));
+            for (int px = 0; px < 4; ++px) Ub[px] = ldsr(ua + (unsigned)((dzf * 16 + px) * 1024));
         }
         rd_slot = rd_slot == 2 ? 0 : rd_slot + 1;
         wr_off = wr_off == 2u * PLANE_BYTES ? 0u : wr_off + (unsigned)PLANE_BYTES;
@@ -623,19 +639,20 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     };
 
     // one input plane = G micro-steps: first, (G - 2 middle ones: one body, looped), last
-    auto plane = [&](auto ph_tag) __attribute__((always_inline)) {
-        step(ph_tag, std::true_type{}, std::false_type{});
+    auto plane = [&](auto ph_tag, auto dz0_tag) __attribute__((always_inline)) {
+        step(ph_tag, std::true_type{}, std::false_type{}, dz0_tag);
         if (G > 2) {
 #pragma nounroll
-            for (int k = 0; k < G - 2; ++k) step(ph_tag, std::false_type{}, std::false_type{});
+            for (int k = 0; k < G - 2; ++k) step(ph_tag, std::false_type{}, std::false_type{}, dz0_tag);
         }
-        step(ph_tag, std::false_type{}, std::true_type{});
+        step(ph_tag, std::false_type{}, std::true_type{}, dz0_tag);
     };
+    plane(std::integral_constant<int, 0>{}, std::true_type{});          // plane s = 0 (z = zb - 1): dz = 0 rows only
 #pragma nounroll
-    for (int sp = 0; sp < nsteps; sp += 3) {
-        plane(std::integral_constant<int, 0>{});
-        if (sp + 1 < nsteps) plane(std::integral_constant<int, 1>{});
-        if (sp + 2 < nsteps) plane(std::integral_constant<int, 2>{});
+    for (int sp = 1; sp < nsteps; sp += 3) {                             // planes 1 .. nsteps - 1, phase = s mod 3
+        plane(std::integral_constant<int, 1>{}, std::false_type{});
+        if (sp + 1 < nsteps) plane(std::integral_constant<int, 2>{}, std::false_type{});
+        if (sp + 2 < nsteps) plane(std::integral_constant<int, 0>{}, std::false_type{});
     }
 }
 
