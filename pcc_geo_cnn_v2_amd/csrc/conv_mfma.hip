@@ -1222,34 +1222,41 @@ __global__ void __launch_bounds__((Cout1Cfg<CIN, KS, S, TZ, TY, TXT>::NT)) conv_
 //     (1) P[tap][voxel] = sum_c w[tap][c] * in[voxel][c]      -- MFMA: M = 27 taps (2 tiles), N = 16 voxels,
 //         K = 16 channels; every input voxel is read ONCE from global memory (coalesced 1 KiB per wave load);
 //     (2) out[z,y,x] = sum_tap P[tap][voxel + offset(tap)]      -- 27 LDS reads + adds per output voxel.
-//   A workgroup owns a 16 x 16 (y,x) column block of one image and marches along z: input plane p feeds the
-//   three output planes p-1, p, p+1 through rolling accumulators, so there is no z halo at all.
+//   A workgroup owns a T x T (y,x) column block of one image (and, with a z split, a slab of it) and marches along z: input
+//   plane p feeds the three output planes p-1, p, p+1 through rolling accumulators.  T = 32 (round 3, when the grid still fills
+//   the CUs): the haloed plane is 34^2 = 1156 voxels for 1024 outputs instead of 18^2 = 324 for 256 -- 13 % halo instead of 27 %
+//   in both the MFMA work (which costs this layer as much time as its HBM floor) and the input reads.
 //   Summation order per output: channels (MFMA chain) -> (ky,kx) -> kz, fixed => deterministic.
 // =====================================================================================================
+template <int T>
 struct Cout1M {
-    static constexpr int NT = 256, TYX = 16;
+    static constexpr int TYX = T, NT = T * T, NW = NT / 64;   // T = 16: 4 waves, 2-3 workgroups per CU; T = 32: 16 waves, one workgroup per CU
     static constexpr int LYX = TYX + 2;                 // haloed plane edge
-    static constexpr int NU = 336;                      // 21 N-tiles x 16 voxels >= 18*18 = 324
-    static constexpr int NTILE = NU / 16;
-    static constexpr int RS = 340;                      // row pitch of P in floats: 4 * RS = 16 (mod 32) -> the four channel quads of a
+    static constexpr int NTILE = (LYX * LYX + 15) / 16; // N-tiles of 16 voxels: 21 (324 voxels) / 73 (1156)
+    static constexpr int NU = NTILE * 16;
+    static constexpr int RS = NU + 4;                   // row pitch of P in floats: 4 * RS = 16 (mod 32) -> the four channel quads of a
                                                         // ds_write_b32 fall on two bank halves (2 cycles, the minimum for 64 lanes) instead of one
-    static constexpr int LDS_BYTES = 32 * RS * 4;          // 32 tap rows: 27 + the zero rows of the second M tile
-    static constexpr int PER_WAVE = (NTILE + 3) / 4;    // N-tiles per wave (6,5,5,5)
+    static_assert((4 * RS) % 32 == 16, "row pitch");
+    static constexpr int LDS_BYTES = 32 * RS * 4;       // 32 tap rows: 27 + the zero rows of the second M tile (43.5 KB / 146.5 KB)
+    static constexpr int PER_WAVE = (NTILE + NW - 1) / NW;    // N-tiles per wave (6,5,5,5 / 5 x9, 4 x7)
 };
 
 // IN16 (fp16 mode, PCC_CONV_IN16): the input is fp16 NDHWC; a lane's 4 channels are one 8-byte load and feed ONE
 // v_mfma_f32_16x16x16_f16 per tap tile instead of four fp32 MFMAs.
-template <bool IN16>
-__global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
-    using C = Cout1M;
+template <bool IN16, int T>
+__global__ void __launch_bounds__((Cout1M<T>::NT)) conv_cout1_mfma_kernel(ConvArgs a) {
+    using C = Cout1M<T>;
     extern __shared__ __attribute__((aligned(16))) float P[];   // [32][RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v = lane & 15, cq = lane >> 4;
     int t = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = t % a.ntx; t /= a.ntx;
-    const int ty = t % a.nty;
-    const int n = t / a.nty;
+    const int ty = t % a.nty; t /= a.nty;
+    const int zs = t % a.ntz;                          // z slab [zb, ze) of output planes
+    const int n = t / a.ntz;
     const int y0 = ty * C::TYX, x0 = tx * C::TYX;
+    const int zlen = (a.D + a.ntz - 1) / a.ntz, zb = zs * zlen, ze = min(zb + zlen, a.D);
+    const int p0 = max(zb - 1, 0), p1 = min(ze, a.D - 1);     // input planes of this slab
 
     // A operand: w[tap = 16*mt + (lane & 15)][channel 4*(lane>>4) + j], taps >= 27 are zero rows
     const f32x4 wA0 = *reinterpret_cast<const f32x4*>(a.w + (0 * 64 + lane) * 4);
@@ -1260,7 +1267,7 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
     int uidx[C::PER_WAVE];
 #pragma unroll
     for (int k = 0; k < C::PER_WAVE; ++k) {
-        const int nt = wave + 4 * k;
+        const int nt = wave + C::NW * k;
         const int u = nt * 16 + v;
         const int ly = u / C::LYX, lx = u - ly * C::LYX;
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
@@ -1283,7 +1290,7 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
     };
 
     // gather side: thread -> output column (y, x)
-    const int oy = tid >> 4, ox = tid & 15;
+    const int oy = tid / C::TYX, ox = tid % C::TYX;
     const bool col_ok = (y0 + oy) < a.OH && (x0 + ox) < a.OW;
     const float* pcol = P + oy * C::LYX + ox;
     const float bias = (a.flags & PCC_CONV_BIAS) ? a.bias[0] : 0.f;
@@ -1301,15 +1308,15 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
 
     f32x4 nxt[C::PER_WAVE];
 #pragma unroll
-    for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = load_in(voff[k], 0);
+    for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = load_in(voff[k], (unsigned)p0 * plane_bytes);
     float accA = 0.f, accB = 0.f, accC = 0.f;   // outputs z = p+1, p, p-1
 
 #pragma unroll 1
-    for (int p = 0; p < a.D; ++p) {
+    for (int p = p0; p <= p1; ++p) {
         f32x4 cur[C::PER_WAVE];
 #pragma unroll
         for (int k = 0; k < C::PER_WAVE; ++k) cur[k] = nxt[k];
-        if (p + 1 < a.D) {
+        if (p + 1 <= p1) {
 #pragma unroll
             for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = load_in(voff[k], (unsigned)(p + 1) * plane_bytes);
         }
@@ -1336,7 +1343,7 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
         // all 32 tap rows are written (rows 27..31 are never read): no lane-dependent branch around the ds_writes
 #pragma unroll
         for (int k = 0; k < C::PER_WAVE; ++k) {
-            if (4 * k + 3 < C::NTILE || wave + 4 * k < C::NTILE) {      // (compile-time for all but the last, partial round of tiles)
+            if (C::NW * k + C::NW - 1 < C::NTILE || wave + C::NW * k < C::NTILE) {      // (compile-time for all but the last, partial round of tiles)
                 float* pw = P + uidx[k] + 4 * cq * C::RS;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1358,11 +1365,11 @@ __global__ void __launch_bounds__(256) conv_cout1_mfma_kernel(ConvArgs a) {
                 s2 += q[(2 * 9 + ky * 3 + kx) * C::RS];
             }
         accA += s0; accB += s1; accC += s2;
-        if (p >= 1) finish(accC, p - 1);
+        if (p - 1 >= zb) finish(accC, p - 1);          // (p - 1 < ze always: p <= ze)
         accC = accB; accB = accA; accA = 0.f;
         __syncthreads();
     }
-    finish(accC, a.D - 1);
+    if (ze == a.D) finish(accC, a.D - 1);              // the last plane of the volume has no plane behind it
 }
 
 #endif  // PCC_PART == 0 (non-template kernel)
@@ -1764,9 +1771,26 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
         PCC_CIN1(16, 3, 2, 8, 4) PCC_CIN1(32, 3, 2, 8, 4) PCC_CIN1(16, 9, 2, 8, 4) PCC_CIN1(32, 9, 2, 8, 4)
 #undef PCC_CIN1
     } else if (p.kind == K_COUT1M) {
-        a.ntz = 1; a.nty = cdiv(a.H, Cout1M::TYX); a.ntx = cdiv(a.W, Cout1M::TYX);
-        if (d->flags & PCC_CONV_IN16) return launch(conv_cout1_mfma_kernel<true>, Cout1M::NT, Cout1M::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
-        return launch(conv_cout1_mfma_kernel<false>, Cout1M::NT, Cout1M::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
+        // 32 x 32 columns (one 16-wave workgroup per CU) when H, W allow it and the grid, z-split into slabs of >= 16 planes, still
+        // gives every CU a workgroup; else 16 x 16 columns, whole z range.  PCC_COUT1_T16=1 forces the latter (A/B runs).
+        static const bool t16 = getenv("PCC_COUT1_T16") != nullptr;
+        if (!t16 && a.H % 32 == 0 && a.W % 32 == 0) {
+            const int base = a.N * (a.H / 32) * (a.W / 32);
+            int zsp = 1;
+            while (base * zsp < ctx->num_cu && a.D / (zsp * 2) >= 16) zsp *= 2;
+            if (base * zsp >= ctx->num_cu) {
+                using C = Cout1M<32>;
+                a.ntz = zsp; a.nty = a.H / 32; a.ntx = a.W / 32;
+                typedef void (*kern_t)(ConvArgs);
+                const kern_t kern = (d->flags & PCC_CONV_IN16) ? (kern_t)conv_cout1_mfma_kernel<true, 32> : (kern_t)conv_cout1_mfma_kernel<false, 32>;
+                { const int rc = pcc_enable_big_lds((const void*)kern, C::LDS_BYTES); if (rc != PCC_OK) return rc; }
+                return launch(kern, C::NT, C::LDS_BYTES, base * zsp, a, st);
+            }
+        }
+        using C = Cout1M<16>;
+        a.ntz = 1; a.nty = cdiv(a.H, C::TYX); a.ntx = cdiv(a.W, C::TYX);
+        if (d->flags & PCC_CONV_IN16) return launch(conv_cout1_mfma_kernel<true, 16>, C::NT, C::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
+        return launch(conv_cout1_mfma_kernel<false, 16>, C::NT, C::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
     } else if (p.kind == K_COUT1) {
 #define PCC_COUT1(CI, K, S, TZ, TY, TXT)                                                                \
     if (ci == CI && k == K && s == S) {                                                                 \

@@ -213,6 +213,29 @@ def test_marching_stride2_concat_offset_and_real_geometry(ctx):
         assert (a[n0:n0 + 1] - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
 
 
+@pytest.mark.parametrize('N,D,HW', [(32, 64, 64), (128, 33, 32), (64, 32, 32)])
+def test_last_layer_32x32_columns_match_reference_order_kernel(ctx, monkeypatch, N, D, HW):
+    """conv_cout1_mfma_kernel<T = 32> (round 3): Conv3DTranspose 16 -> 1 k3 s1 + bias + ReLU (the last synthesis layer,
+    /root/reference/src/model_transforms.py:137) on 32 x 32 columns with z slabs -- the bench launch (64^3 x 32: 256 workgroups of
+    two 32-plane slabs), an odd depth (slabs of 17 and 16 planes) -- against the generic reference-order kernel and the 16 x 16
+    column variant; deterministic."""
+    rng = np.random.default_rng(D)
+    w = (rng.standard_normal((3, 3, 3, 1, 16)) / np.sqrt(27 * 16)).astype(np.float32)
+    layer = ops.ConvLayer(w, np.array([0.1], np.float32), 1, True, True)
+    x = torch.randn((N, D, HW, HW, 16), generator=torch.Generator().manual_seed(D)).to(ctx.device)
+    a = ops.conv3d(ctx, x, layer)
+    a2 = ops.conv3d(ctx, x, layer)
+    monkeypatch.setenv('PCC_COUT1_T16', '1')
+    b = ops.conv3d(ctx, x, layer)
+    monkeypatch.delenv('PCC_COUT1_T16')
+    torch.cuda.synchronize()
+    assert torch.equal(a, a2)
+    assert (a - b).abs().max().item() <= 2e-5 * (1 + b.abs().max().item())
+    for n0 in (0, N // 2, N - 1):
+        ref = ops.conv3d(ctx, x[n0:n0 + 1].contiguous(), layer, impl=L.PCC_IMPL_GENERIC)
+        assert (a[n0:n0 + 1] - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+
+
 # stated tolerance of the fp16-MFMA mode (BASELINE.json configs[4]): operands rounded to fp16 (2^-11 relative), fp32
 # accumulation over <= 27*64 products -> |err| <= 4e-3 * (1 + max|ref|) against the double-accumulation oracle
 TOL_F16 = 4e-3
