@@ -305,11 +305,14 @@ static int tr2m_zsplit(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     return zs;
 }
 
-// AUTO dispatch: 32 -> 16 always; 64 -> 32 only on slabs of >= 8 planes (16^3 x 32 blocks gives 4-plane slabs: the 9-tap halo
-// plane and the 108 KB weight prologue per workgroup make the tiled conv_tr2g_kernel faster there: 127 vs 135 us)
+// AUTO dispatch: 32 -> 16 always; 64 -> 32 from 32 input planes up (16^3 x 32 blocks gives 4-plane slabs: the 9-tap halo plane and
+// the 108 KB weight prologue per workgroup make the tiled conv_tr2g_kernel faster there: 127 vs 135 us).  The rule must not
+// depend on the batch size: the two kernels sum in different orders, and encoder and decoder (which may chunk differently) have
+// to produce the same bits.
 bool pcc_tr2m_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d) {
+    (void)ctx;
     if (!pcc_tr2m_eligible(d)) return false;
-    return d->Cin == 32 || d->D / tr2m_zsplit(ctx, d) >= 8;
+    return d->Cin == 32 || d->D >= 32;
 }
 
 int pcc_conv_tr2m(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_tr2g, const float* bias, float* out,

@@ -229,8 +229,9 @@ def test_last_layer_32x32_columns_match_reference_order_kernel(ctx, monkeypatch,
     b = ops.conv3d(ctx, x, layer)
     monkeypatch.delenv('PCC_COUT1_T16')
     torch.cuda.synchronize()
-    assert torch.equal(a, a2)
-    assert (a - b).abs().max().item() <= 2e-5 * (1 + b.abs().max().item())
+    # same bits as the 16 x 16 columns (per output: channels -> (ky, kx) -> kz, whatever the column / slab geometry): encoder
+    # and decoder may chunk differently and still have to agree on x_hat
+    assert torch.equal(a, a2) and torch.equal(a, b)
     for n0 in (0, N // 2, N - 1):
         ref = ops.conv3d(ctx, x[n0:n0 + 1].contiguous(), layer, impl=L.PCC_IMPL_GENERIC)
         assert (a[n0:n0 + 1] - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
