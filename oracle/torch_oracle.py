@@ -64,6 +64,73 @@ def run_transform(name, filters, params, prefix, x):
     return x.numpy() if isinstance(x, torch.Tensor) else x
 
 
+def _h(t):
+    """round to fp16 (RTNE, what v_cvt_pk_f16_f32 does) and back"""
+    return torch.as_tensor(t, dtype=torch.float32).to(torch.float16).to(torch.float32)
+
+
+def run_transform_fp16(name, filters, params, prefix, x):
+    """The fp16 mode of the BUILD (BASELINE.json configs[4]; the reference has no such mode) restated on the CPU: the same layer
+    lists, every operand rounded to fp16 exactly where pcc_geo_cnn_v2_amd/csrc/network.hip + conv_f16.hip + the PCC_CONV_F16
+    kernels of conv_mfma.hip round it, products accumulated in fp32 (oneDNN: another summation order than the MFMA chains):
+
+      * a block (stride-2 layer with res = 'save' and 16 / 32 / 64 output channels on a grid of 16-multiples, followed by its two
+        k3 stride-1 layers) keeps its two intermediate tensors in fp16: layer 0 rounds its output (after bias + ReLU), layer 1
+        reads and writes fp16, layer 2 reads fp16, adds the fp16 residual in fp32 and writes fp32 -- or fp16 when its only consumer
+        is the final 16 -> 1 layer;
+      * 64-channel layers of a block: the products of input channels 0..31 are rounded to fp16 before those of 32..63 are added;
+      * every other layer rounds both operands to fp16 at the matrix instruction and writes fp32; the Cin = 1 first layer computes
+        in fp32 (its input is 0 / 1).
+    Test infrastructure for tests/test_codec_gpu.py (stage check of the fp16 graph)."""
+    from . import oracle as O
+    layers = O.transform_layers(name, filters)
+    x = torch.as_tensor(x, dtype=torch.float32)
+    t1, left, final_in16 = None, 0, False
+    for i, (kind, cout, k, s, bias, relu, res) in enumerate(layers):
+        fn = conv3d if kind == 'conv' else conv3d_transpose
+        w = torch.as_tensor(params[f'{prefix}/{i}/kernel'], dtype=torch.float32)
+        b = params.get(f'{prefix}/{i}/bias') if bias else None
+        cin = x.shape[-1]
+        H, W = x.shape[2], x.shape[3]
+        oH, oW = (2 * H, 2 * W) if kind == 'convT' else (H // 2, W // 2)
+        last = i + 1 == len(layers)
+        starts = (res == 'save' and s == 2 and k == 3 and cout in (16, 32, 64) and oH % 16 == 0 and oW % 16 == 0 and H % 2 == 0
+                  and W % 2 == 0 and i + 2 < len(layers) and layers[i + 1][6] is None and layers[i + 2][6] == 'add'
+                  and layers[i + 1][2:4] == (3, 1) and layers[i + 2][2:4] == (3, 1))
+        in16 = out16 = False
+        if starts:
+            out16, left = True, 2
+        elif left == 2:
+            in16, out16, left = True, True, 1
+        elif left == 1:
+            in16, left = True, 0
+            if i + 2 == len(layers) and layers[i + 1][0] == 'convT' and layers[i + 1][1:4] == (1, 3, 1) and cout == 16:
+                out16 = final_in16 = True
+        elif last and final_in16:
+            in16 = True
+        if in16 and cout == 64 and not last:        # conv_f16 C = 64: two input halves, fp16 partial sums in between
+            if kind == 'conv':
+                part = fn(x[..., :32], _h(w[..., :32, :]), None, s, False)
+                y = _h(part) + fn(x[..., 32:], _h(w[..., 32:, :]), None, s, False)
+            else:
+                part = fn(x[..., :32], _h(w[..., :32]), None, s, False)
+                y = _h(part) + fn(x[..., 32:], _h(w[..., 32:]), None, s, False)
+            if b is not None:
+                y = y + torch.as_tensor(b, dtype=torch.float32)
+            if relu:
+                y = F.relu(y)
+        elif cin == 1:
+            y = fn(x, w, b, s, relu)                 # conv_cin1_kernel: fp32 arithmetic
+        else:
+            y = fn(x if in16 else _h(x), _h(w), b, s, relu)
+        if res == 'save':
+            t1 = _h(y) if out16 else y               # the residual is what was stored
+        elif res == 'add':
+            y = t1 + y
+        x = _h(y) if out16 else y
+    return x.numpy()
+
+
 def codec_block_roundtrip(model, x):
     """One block through the compress graph + the decompress graph + fixed-threshold extraction,
     batch 1, exactly the unit of work of SURVEY.md §8d.  Conv stacks via oneDNN, entropy coding and

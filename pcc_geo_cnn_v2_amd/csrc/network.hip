@@ -268,8 +268,18 @@ PCC_API int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters
         if ((layer_flags & PCC_CONV_F16) && L.res == 1 && L.stride == 2 && L.k == 3 && (L.cout == 16 || L.cout == 32 || L.cout == 64) &&
             oH % 16 == 0 && oW % 16 == 0 && H % 2 == 0 && W % 2 == 0 && i + 2 < v.size() && v[i + 1].res == 0 && v[i + 2].res == 2 &&
             v[i + 1].k == 3 && v[i + 1].stride == 1 && v[i + 2].k == 3 && v[i + 2].stride == 1 &&
-            [&] { const pcc_conv_desc d0 = layer_desc(L, im[i].cin, N, D, H, W, layer_flags); return pcc_conv_mfma_supported(&d0) == 1; }()) {
-            storage = PCC_CONV_OUT16;       // (a layer on the generic path cannot hand over in fp16)
+            [&] {   // every layer of the block must be able to take its fp16 role: pcc_conv3d has no fallback for IN16 / RES16
+                const pcc_conv_desc d0 = layer_desc(L, im[i].cin, N, D, H, W, layer_flags);
+                if (pcc_conv_mfma_supported(&d0) != 1) return false;     // (a layer on the generic path cannot hand over in fp16)
+                int bD = D, bH = H, bW = W;
+                out_dims(L, bD, bH, bW);
+                for (size_t q = i + 1; q <= i + 2; ++q) {
+                    const pcc_conv_desc dq = layer_desc(v[q], im[q].cin, N, bD, bH, bW, layer_flags | PCC_CONV_IN16);
+                    if (pcc_conv_mfma_supported(&dq) != 1 || !pcc_f16_eligible(&dq)) return false;
+                }
+                return true;
+            }()) {
+            storage = PCC_CONV_OUT16;
             f16_block_left = 2;
         } else if (f16_block_left == 2) {
             storage = PCC_CONV_IN16 | PCC_CONV_OUT16;
@@ -279,7 +289,9 @@ PCC_API int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters
             f16_block_left = 0;
             // the block's output stays fp16 when its only consumer is the final 16 -> 1 transposed conv (which then reads 8 B
             // per lane and contracts with one fp16 MFMA)
-            if (i + 2 == v.size() && v[i + 1].transposed && v[i + 1].cout == 1 && v[i + 1].k == 3 && v[i + 1].stride == 1 && L.cout == 16) {
+            if (i + 2 == v.size() && v[i + 1].transposed && v[i + 1].cout == 1 && v[i + 1].k == 3 && v[i + 1].stride == 1 && L.cout == 16 &&
+                [&] { const pcc_conv_desc df = layer_desc(v[i + 1], im[i + 1].cin, N, D, H, W, layer_flags | PCC_CONV_IN16);
+                      return pcc_conv_mfma_supported(&df) == 1; }()) {
                 storage |= PCC_CONV_OUT16;
                 final_in16 = true;
             }
