@@ -141,12 +141,19 @@ def compute_optimal_thresholds(block, x_hat, thresholds, resolution, normals=Non
 
 class HostSearchPool:
     """Persistent pool of worker PROCESSES (pcc_geo_cnn_v2_amd.search_worker) for the host KD-tree part of the threshold
-    search: the blocks of a chunk are independent, the reference searches them one after the other (model_types.py:192-212).
+    search: the blocks of a cloud are independent, the reference searches them one after the other (model_types.py:192-212).
     Subprocesses with pipes instead of multiprocessing: no fork of a process that holds a HIP context, no re-import of the
-    caller's __main__.  A worker that dies is replaced and the failure reported with its exit status."""
+    caller's __main__.  Jobs go through one queue (`submit` returns a future), so the encoder can hand over the blocks of many
+    chunks while the GPU works on the next ones; a worker that dies is replaced and the failure reported with its exit status."""
 
     def __init__(self, n_workers):
+        import queue
+        import threading
         self.procs = [self._spawn() for _ in range(max(1, int(n_workers)))]
+        self._q = queue.Queue()
+        self._threads = [threading.Thread(target=self._drive, args=(w,), daemon=True) for w in range(len(self.procs))]
+        for t in self._threads:
+            t.start()
 
     @staticmethod
     def _spawn():
@@ -170,34 +177,48 @@ class HostSearchPool:
             body = p.stdout.read(struct.unpack('<Q', hdr)[0]) if len(hdr) == 8 else b''
             if len(hdr) < 8 or len(body) < struct.unpack('<Q', hdr)[0]:
                 raise EOFError('short read')
-        except (EOFError, BrokenPipeError, OSError) as e:
+        except (EOFError, BrokenPipeError, OSError, ValueError) as e:
             p.kill()
             code = p.wait()
             self.procs[w] = self._spawn()       # the pool stays usable
             raise RuntimeError(f'threshold search worker {w} died (exit status {code}, {e}); it has been restarted') from e
         return pickle.loads(body)
 
-    def map(self, jobs):
-        """jobs, each one of
-             ('decide', block, x_hat, thresholds, resolution, with_normals, opt_metrics, max_deltas) -> (names, best)
-             ('tally', block, x_hat, thresholds, with_normals)                                      -> (tallies, mean_tally)
-           (a bare 7-tuple is a 'decide' job).  Results in order; worker i handles jobs i, i + W, ... through its own pipe."""
-        from concurrent.futures import ThreadPoolExecutor
-        W = len(self.procs)
-        out = [None] * len(jobs)
-
-        def drive(w):
-            for i in range(w, len(jobs), W):
-                status, a, b = self._exchange(w, jobs[i])
+    def _drive(self, w):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            job, fut = item
+            try:
+                status, a, b = self._exchange(w, job)
                 if status != 'ok':
                     raise AssertionError(f'threshold search worker: {a}')
-                out[i] = (a, b)
+                fut.set_result((a, b))
+            except BaseException as e:      # delivered to whoever waits for this job
+                fut.set_exception(e)
 
-        with ThreadPoolExecutor(max_workers=W) as ex:
-            list(ex.map(drive, range(min(W, len(jobs)))))
-        return out
+    def submit(self, job):
+        """job: ('decide', block, x_hat, thresholds, resolution, with_normals, opt_metrics, max_deltas) -> (names, best)
+                ('tally', block, x_hat, thresholds, with_normals)                                      -> (tallies, mean_tally)
+           (a bare 7-tuple is a 'decide' job).  Returns a concurrent.futures.Future."""
+        from concurrent.futures import Future
+        assert self.procs, 'pool is closed'
+        fut = Future()
+        self._q.put((job, fut))
+        return fut
+
+    def map(self, jobs):
+        """Results of `jobs` in order (first failure re-raised)."""
+        futs = [self.submit(j) for j in jobs]
+        return [f.result() for f in futs]
 
     def close(self):
+        for _ in getattr(self, '_threads', []):
+            self._q.put(None)
+        for t in getattr(self, '_threads', []):
+            t.join(timeout=5)
+        self._threads = []
         for p in self.procs:
             try:
                 p.stdin.close()
@@ -207,7 +228,10 @@ class HostSearchPool:
         self.procs = []
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def gpu_search_supported(opt_metrics, dhw):
@@ -236,18 +260,12 @@ def d1_tallies_gpu(ctx, blocks, x_hat, thresholds):
     return out
 
 
-def compute_optimal_thresholds_gpu(ctx, blocks, x_hat, thresholds, resolution, opt_metrics=('d1_mse',),
-                                   max_deltas=(np.inf,), d2_stats=None):
-    """compute_optimal_thresholds for a batch of blocks with the KD-tree work of the d1_* metrics replaced by exact distance
-    transforms on the GPU.  `d2_stats`: per block (tallies, mean_tally) from the host pool when d2_* metrics are requested --
-    or a callable returning that list, evaluated after the GPU work has been issued so both run concurrently (their D2 slots
-    are merged into the GPU's table; the D1 slots of both sources are the same integers, which is asserted).
-    Returns (names, [best thresholds per block])."""
+def decide_from_tallies(blocks, d1, n_thresholds, resolution, opt_metrics, max_deltas, d2_stats=None):
+    """Decisions of a chunk from the GPU's D1 tallies (d1_tallies_gpu), merged with the host pool's (tallies, mean_tally) per
+    block when d2_* metrics are requested: their D2 slots go into the GPU's table; the D1 slots of both sources are the same
+    integers, which is asserted.  Returns (names, [best thresholds per block])."""
     validate_opt_metrics(opt_metrics, with_normals=d2_stats is not None)
-    d1 = d1_tallies_gpu(ctx, blocks, x_hat, thresholds)
-    if callable(d2_stats):
-        d2_stats = d2_stats()
-    names, best = None, []
+    names, best = metric_names(list(opt_metrics), list(max_deltas)), []
     for i, blk in enumerate(blocks):
         tallies, mean_tally = d1[i], mean_point_d1_tally(blk)
         if d2_stats is not None:
@@ -256,7 +274,17 @@ def compute_optimal_thresholds_gpu(ctx, blocks, x_hat, thresholds, resolution, o
             assert np.array_equal(host_t[:, :3], tallies[:, :3]), 'host KD-tree and GPU distance-transform D1 sums differ'
             tallies[:, [PM.D2_AB, PM.D2_BA]] = host_t[:, [PM.D2_AB, PM.D2_BA]]
             mean_tally[[PM.D2_AB, PM.D2_BA]] = host_mean[[PM.D2_AB, PM.D2_BA]]
-        names, bt = select_thresholds_from_stats(len(blk), tallies, mean_tally, len(thresholds), resolution,
-                                                 list(opt_metrics), list(max_deltas))
+        names, bt = select_thresholds_from_stats(len(blk), tallies, mean_tally, n_thresholds, resolution, list(opt_metrics), list(max_deltas))
         best.append(bt)
     return names, best
+
+
+def compute_optimal_thresholds_gpu(ctx, blocks, x_hat, thresholds, resolution, opt_metrics=('d1_mse',),
+                                   max_deltas=(np.inf,), d2_stats=None):
+    """compute_optimal_thresholds for a batch of blocks with the KD-tree work of the d1_* metrics replaced by exact distance
+    transforms on the GPU.  `d2_stats`: per block (tallies, mean_tally) from the host pool when d2_* metrics are requested -- or
+    a callable returning that list, evaluated after the GPU work has been issued.  Returns (names, [best thresholds per block])."""
+    d1 = d1_tallies_gpu(ctx, blocks, x_hat, thresholds)
+    if callable(d2_stats):
+        d2_stats = d2_stats()
+    return decide_from_tallies(blocks, d1, len(thresholds), resolution, opt_metrics, max_deltas, d2_stats)

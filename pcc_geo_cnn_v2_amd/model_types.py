@@ -25,7 +25,7 @@ from . import _lib as L
 from . import model_transforms as MT
 from . import ops
 from .entropy_models import EntropyBottleneck, GaussianConditional, scale_table
-from .model_opt import compute_optimal_thresholds_gpu, gpu_search_supported, metric_names
+from .model_opt import d1_tallies_gpu, decide_from_tallies, gpu_search_supported, metric_names
 from .model_transforms import TransformType
 from .utils.octree_coding import departition_octree
 from .utils.pc_metric import cloud_metrics_batch
@@ -235,7 +235,10 @@ class CompressionModel:
 
     def _search_pool(self, n_jobs):
         from .model_opt import HostSearchPool
-        want = max(1, min(n_jobs, self.search_threads or min(os.cpu_count() or 1, 64)))
+        # default: the cores this process may run on, at most 64 (measured on a 256-thread box whose container gets far fewer: 64
+        # workers 17.5 s per 190-block cloud with d2 metrics, 128 workers 23.6 s -- the KD-tree work is host-bound)
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        want = max(1, min(n_jobs, self.search_threads or min(usable, 64)))
         pool = getattr(self, '_host_search_pool', None)
         if pool is None or len(pool.procs) < want:
             if pool is not None:
@@ -361,6 +364,31 @@ class CompressionModel:
         strings_list, threshold_list, debug_t_list, x_hat_list = [], [], [], []
         opt_metrics_ret = metric_names(opt_metrics, max_deltas)
         half = len(self.thresholds) // 2
+        SEARCH_LAG = 8            # chunks whose x_hat (batch x 1 MiB) stays on the GPU while their host jobs are in the pool
+        pending = []
+
+        def finalize_search(item):
+            """decisions + candidate point lists of one chunk whose tallies (GPU) / host results are complete"""
+            nonlocal opt_metrics_ret
+            chunk_, x_hat_ = item['chunk'], item['x_hat']
+            n_m = len(max_deltas) * len(opt_metrics)
+            host = [f.result() for f in item['futures']] if item['futures'] is not None else None
+            if item['d1'] is not None:
+                opt_metrics_ret, best_all = decide_from_tallies(chunk_, item['d1'], len(self.thresholds), resolution, opt_metrics, max_deltas, host)
+            else:
+                opt_metrics_ret, best_all = host[0][0], [bt for _, bt in host]
+            # a block whose decode is empty at every threshold returns len(opt_metrics) entries (model_opt.py:35-36); with
+            # more than one max_delta the reference's zip(*...) would silently drop the other candidates of the WHOLE
+            # cloud -- here the 'emit nothing' index is repeated instead
+            best_all = [list(bt) + [bt[-1]] * (n_m - len(bt)) for bt in best_all]
+            per_metric = []
+            for m in range(n_m):
+                xyz, counts = self._extract_points(ctx, x_hat_, [bt[m] for bt in best_all], clip=True)
+                per_metric.append(self._gather_points(xyz, counts))
+            for j in range(len(chunk_)):
+                threshold_list.append(list(best_all[j]))
+                x_hat_list.append([per_metric[m][j] for m in range(n_m)])
+
         for c0 in range(0, len(blocks), self.batch_size):
             chunk = blocks[c0:c0 + self.batch_size]
             x = self._voxelize(ctx, chunk, dhw)
@@ -380,15 +408,14 @@ class CompressionModel:
                 # normals in the input.  d2_* metrics: the reference's numbers depend on WHICH of several equidistant nearest
                 # neighbours scipy's KD-tree returns (measured: another tie rule moves d2_mse by up to 60 % and the chosen
                 # threshold in 2 of 6 blocks), so those tallies come from the same KD-trees on the host -- one block per
-                # worker process of a persistent pool (the reference runs the blocks one after the other), concurrently
-                # with the GPU's d1 search; the decisions are taken on the merged table.
-                n_m = len(max_deltas) * len(opt_metrics)
+                # worker process of a persistent pool (the reference runs the blocks one after the other).  The host jobs of a
+                # chunk are only QUEUED here; the GPU goes on with the next chunks and the decisions are taken (on the merged
+                # table) a few chunks later, so the pool always holds several chunks' worth of blocks.
                 want_d2 = any(m.startswith('d2_') for m in opt_metrics)
                 on_gpu = gpu_search_supported(opt_metrics, dhw)
                 strings = enc['finish']()
-                host_future = None
+                item = dict(chunk=chunk, x_hat=x_hat, futures=None, d1=None)
                 if want_d2 or not on_gpu:
-                    from concurrent.futures import ThreadPoolExecutor
                     xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)
                     # blocks go over in their own dtype: the worker computes exactly what the in-process call would
                     if on_gpu:
@@ -398,29 +425,17 @@ class CompressionModel:
                                  list(opt_metrics), list(max_deltas)) for j in range(len(chunk))]
                     self.host_search_jobs = getattr(self, 'host_search_jobs', 0) + len(jobs)
                     self.last_host_job_kind = jobs[0][0] if jobs else None
-                    if not hasattr(self, '_search_thread'):
-                        self._search_thread = ThreadPoolExecutor(max_workers=1)
-                    host_future = self._search_thread.submit(self._search_pool(len(chunk)).map, jobs)
+                    pool = self._search_pool(len(blocks))
+                    item['futures'] = [pool.submit(job) for job in jobs]
                 if on_gpu:
-                    opt_metrics_ret, best_all = compute_optimal_thresholds_gpu(
-                        ctx, chunk, x_hat, self.thresholds, resolution, opt_metrics, max_deltas,
-                        d2_stats=host_future.result if host_future is not None else None)
-                else:
-                    res = host_future.result()
-                    opt_metrics_ret, best_all = res[0][0], [bt for _, bt in res]
-                # a block whose decode is empty at every threshold returns len(opt_metrics) entries (model_opt.py:35-36); with
-                # more than one max_delta the reference's zip(*...) would silently drop the other candidates of the WHOLE
-                # cloud -- here the 'emit nothing' index is repeated instead
-                best_all = [list(bt) + [bt[-1]] * (n_m - len(bt)) for bt in best_all]
-                per_metric = []
-                for m in range(n_m):
-                    xyz, counts = self._extract_points(ctx, x_hat, [bt[m] for bt in best_all], clip=True)
-                    per_metric.append(self._gather_points(xyz, counts))
-                for j in range(len(chunk)):
-                    threshold_list.append(list(best_all[j]))
-                    x_hat_list.append([per_metric[m][j] for m in range(n_m)])
+                    item['d1'] = d1_tallies_gpu(ctx, chunk, x_hat, self.thresholds)
+                pending.append(item)
+                if len(pending) > SEARCH_LAG:
+                    finalize_search(pending.pop(0))
             strings_list.extend(strings)
             debug_t_list.extend(enc['debug'])
+        while pending:
+            finalize_search(pending.pop(0))
         return strings_list, threshold_list, x_hat_list, opt_metrics_ret, debug_t_list
 
     def compress_blocks(self, sess, blocks, binstr, points, resolution, level, with_normals=False,

@@ -1,0 +1,37 @@
+"""GPU box: seconds per cloud of the adaptive threshold search on the 190-block stand-in for longdress (thin shell @1024^3, level 4),
+c3p, with normals -- the reference's experiment setting opt_metrics ['d1_mse', 'd2_mse'] (ev_experiment.yml:47), and d1 only.
+  round 2: any normals -> every metric on the host KD-tree pool ('decide' jobs);
+  round 3: d1_* from the GPU distance transforms, only the D2 tallies from the host pool ('tally' jobs, B->A neighbours queried once)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from pcc_geo_cnn_v2_amd import ops, model_opt
+from pcc_geo_cnn_v2_amd.model_configs import ModelConfigType
+from pcc_geo_cnn_v2_amd.utils.octree_coding import partition_octree
+ctx = ops.get_context(torch.device('cuda', 0))
+R, level, res = 1024, 4, 64
+rng = np.random.default_rng(0)
+u = rng.standard_normal((3_000_000, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+pts, first = np.unique(np.round(u * 200 + np.array([512, 500, 520])).astype(np.int64), axis=0, return_index=True)
+cloud = np.hstack([pts.astype(np.float64), u[first]])
+blocks, binstr = partition_octree(cloud, [0, 0, 0], [R] * 3, level)
+model = ModelConfigType['c3p'].build(batch_size=32); model.compress([1, 1, res, res, res])
+model.set_weights(bench.synthetic_weights(model))
+print(f'{len(pts)} points, {len(blocks)} blocks, host cores {os.cpu_count()}, usable {len(os.sched_getaffinity(0))}')
+def run(mets, host_only=False):
+    if host_only:
+        keep = model_opt.gpu_search_supported
+        import pcc_geo_cnn_v2_amd.model_types as MTY
+        MTY.gpu_search_supported = lambda *a: False
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = model.encode_block_range(ctx, blocks, R, with_normals=True, opt_metrics=mets, max_deltas=[np.inf])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if host_only:
+        MTY.gpu_search_supported = keep
+    return dt, out[1]
+run(['d1_mse'])                                      # warm-up (pool start, kernels)
+for mets in (['d1_mse'], ['d1_mse', 'd2_mse']):
+    t_new, thr_new = run(mets)
+    t_old, thr_old = run(mets, host_only=True)
+    print(f'{mets}: round-3 dispatch {t_new:.2f} s / cloud, all-host (round-2 behaviour with normals) {t_old:.2f} s / cloud, {t_old / t_new:.1f}x; decisions equal: {thr_new == thr_old}; jobs {model.last_host_job_kind}')
