@@ -2,14 +2,14 @@
 # Runs on the GPU box (via gpurun): rocprofv3 evidence for profiles/.  Usage: tools/profile_round.sh <tag>
 # No trace domain other than --kernel-trace is ever combined with --pmc (gpurun refuses that), counters in separate passes.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 # (1) per-kernel time of the benchmark command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 180 python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 180 python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_profiled.log 2>&1
 # (2) counters of the three kernels VERDICT names, separate passes each: <key> <bench_one shape>
 pmc() {
   KEY=$1; shift
@@ -22,7 +22,10 @@ pmc() {
   PCC_BENCH_IMPL=0 timeout 120 $CMD 2>&1 | grep -v amdgpu.ids > $OUT/$KEY/time.log
 }
 pmc wino16 32 64 16 16 3 1 1 res
-pmc tr2g 32 32 32 16 3 2 1
+pmc cin32 32 32 32 32 3 1 1 res
+pmc cin64 32 16 64 64 3 1 1 res
+pmc tr2m 32 32 32 16 3 2 1
+pmc tr2g 32 16 64 32 3 2 1
 pmc cout1 32 64 16 1 3 1 1
 # (3) un-profiled bench line for comparison
 cd $R && python bench.py --steps 20 --warmup 3 > $OUT/bench.log 2>&1

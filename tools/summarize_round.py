@@ -1,6 +1,6 @@
 """Turns gpurun_out/<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/."""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 os.makedirs(dst, exist_ok=True)
@@ -15,9 +15,15 @@ B = 32
 KERNELS = {
     'wino16': ('conv16_wino_kernel', 'Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32 (Winograd F(2x2,3x3) x-y + direct z)',
                2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'mfma'),
-    'tr2g': ('conv_tr2g_kernel', 'Conv3DTranspose 32->16 k3 s2 32^3 -> 64^3, batch 32 (parity-decomposed, persistent)',
+    'cin32': ('conv16_wino_cin_kernel<true, 2>', 'Conv3DTranspose 32->32 k3 s1 @32^3 + residual, batch 32 (Winograd, cin groups inside the z march)',
+              2.0 * B * 32 ** 3 * 27 * 32 * 32, B * 32 ** 3 * 32 * 4 * 3, 'mfma'),
+    'cin64': ('conv16_wino_cin_kernel<true, 4>', 'Conv3DTranspose 64->64 k3 s1 @16^3 + residual, batch 32 (Winograd, cin groups inside the z march, U streamed)',
+              2.0 * B * 16 ** 3 * 27 * 64 * 64, B * 16 ** 3 * 64 * 4 * 3, 'mfma'),
+    'tr2m': ('conv_tr2m_kernel', 'Conv3DTranspose 32->16 k3 s2 32^3 -> 64^3, batch 32 (parity-decomposed, z-marching, LDS-resident weights)',
              2.0 * B * 32 ** 3 * 27 * 32 * 16, B * (32 ** 3 * 32 + 64 ** 3 * 16) * 4, 'mfma'),
-    'cout1': ('conv_cout1_mfma_kernel', 'Conv3DTranspose 16->1 k3 s1 @64^3, batch 32 (tap-plane MFMA + LDS gather)',
+    'tr2g': ('conv_tr2g_kernel', 'Conv3DTranspose 64->32 k3 s2 16^3 -> 32^3, batch 32 (parity-decomposed, tiled persistent kernel)',
+             2.0 * B * 16 ** 3 * 27 * 64 * 32, B * (16 ** 3 * 64 + 32 ** 3 * 32) * 4, 'mfma'),
+    'cout1': ('conv_cout1_mfma_kernel', 'Conv3DTranspose 16->1 k3 s1 @64^3, batch 32 (tap-plane MFMA + LDS gather, 32 x 32 columns)',
               2.0 * B * 64 ** 3 * 27 * 16, B * 64 ** 3 * (16 + 1) * 4, 'hbm'),
 }
 rows, traffic_json = [], None
@@ -66,10 +72,10 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
 json.dump(traffic_json, open(os.path.join(dst, 'dominant_kernel_traffic.json'), 'w'), indent=1)
 json.dump(rows, open(os.path.join(dst, f'{tag}_kernel_counters.json'), 'w'), indent=1)
 with open(os.path.join(dst, f'{tag}_bench_kernel_summary.md'), 'w') as f:
-    f.write(f'# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline`\n\n')
+    f.write(f'# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary`\n\n')
     f.write('6 steps of 32 blocks (1 warm-up + 5 timed), c3p @64^3, per (kernel, grid size):\n\n' + summary + '\n')
     f.write('bench.py JSON under the profiler:\n\n```\n' + ''.join(bench_prof) + '```\n\nbench.py JSON without the profiler (same box):\n\n```\n' + ''.join(bench) + '```\n\n')
-    f.write('## Counters of the three kernels VERDICT r01 names (separate `--pmc` passes on `tools/bench_one.py`, batch 32)\n\n')
+    f.write('## Counters of the kernels the verdicts name (separate `--pmc` passes on `tools/bench_one.py`, batch 32)\n\n')
     f.write('| kernel | launch us (median, un-profiled) | executed MFMA GFLOP | executed frac of 157.3 TF | MFMA busy / SIMD cycles | MFMA busy / wave cycles | clock GHz (counter pass) | '
             'HBM bytes / algorithmic | algorithmic TB/s (frac of 8) | wait_any | LDS conflict frac |\n|---|---|---|---|---|---|---|---|---|---|---|\n')
     for o in rows:
