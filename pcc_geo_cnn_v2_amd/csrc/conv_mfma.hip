@@ -163,8 +163,10 @@ conv_fwd_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(C::NG * NTAP * C::NCT) * 1024u);
     const unsigned wlane = lane * 16;
     // weights: RING-deep register prefetch ring over the linear (g, tap) sequence; the loads are pinned
-    // two taps ahead of their use (>= 1000 cycles of MFMA work) so L2 latency never reaches the MFMA pipe.
-    constexpr int RING = (KS == 3) ? 3 : 5;
+    // RING - 1 taps ahead of their use so that L2 latency (500-900 cycles) never reaches the MFMA pipe.  A tap is R * CTW * 4 MFMAs:
+    // two taps ahead are >= 1000 cycles for the big tiles, but only 256 for the R = CTW = 1 tiles of the 4^3 / 8^3 grids (round 3:
+    // those layers were latency-bound on exactly this -- 64 -> 64 @4^3 26.5 us for 5 us of MFMAs), hence the deeper rings there.
+    constexpr int RING = (KS == 3) ? (R * CTW == 1 ? (TX <= 4 ? 27 : 9) : (R * CTW == 2 ? 9 : 3)) : 5;      // (8-wide grids: 27 costs occupancy, 39.5 vs 36.4 us)
     constexpr int SLAB = (KS == 3) ? NTAP : KS * KS;   // taps unrolled per dynamic iteration
     static_assert(SLAB % RING == 0, "ring phase must be static");
     const int q_last = C::NG * NTAP - 1;
@@ -647,8 +649,11 @@ conv_tr2_kernel(ConvArgs a) {
     // FULL: the whole (class, tap, g) sequence is unrolled so that a static 3-deep register ring prefetches two
     // units ahead.  For the widest shape (64 -> 64: 3456 MFMAs per wave) that would not fit the instruction
     // cache, so the cin-group loop stays dynamic there and the weights are loaded per (tap, group).
-    constexpr bool FULL = C::NG * CTW < 16 && C::NG * C::NCT < 16;
-    constexpr int RING = 3;
+    // (round 3) the one-row, one-cout-tile configuration of the 4-wide grids is small enough to unroll whatever the width (432
+    // MFMAs per wave) and needs a deep ring: a unit is 4 MFMAs = 128 cycles there, and loading per (tap, group) on demand left the
+    // 64 -> 64 4^3 -> 8^3 layer at 53 us for 6 us of MFMAs.
+    constexpr bool FULL = (C::NG * CTW < 16 && C::NG * C::NCT < 16) || R * CTW == 1;
+    constexpr int RING = R * CTW == 1 ? 12 : 3;
     f32x4 wf[RING][CTW];
     if constexpr (FULL) {
 #pragma unroll
