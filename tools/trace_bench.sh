@@ -1,4 +1,5 @@
-R=$(pwd); OUT=$R/gpurun_out/r03r; rm -rf $OUT; mkdir -p $OUT
+# GPU box: rocprofv3 kernel trace of bench.py (7 steps), conv kernels only, per (kernel, grid)
+R=$(pwd); OUT=$R/gpurun_out/trace_bench; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 300 python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_profiled.log 2>&1
 cd $R
