@@ -283,6 +283,15 @@ int pcc_range_encode_batch(const pcc_cdf_table* t, int32_t n_streams, const int3
 int pcc_range_decode_batch(const pcc_cdf_table* t, int32_t n_streams, const uint8_t* const* str,
                            const size_t* str_len, const int32_t* const* index, int32_t index_mod,
                            const size_t* n, int32_t* const* out, int32_t n_threads);
+/* The same coders on narrow host arrays (round 3): data_bytes / out_bytes 2 (int16) or 4 (int32) symbols, index_bytes 1 (uint8)
+ * or 4 (int32) CDF rows -- the codec moves y symbols as int16 and the 64 Gaussian scale rows as uint8 across PCIe.  Decoding
+ * into 16 bits returns PCC_ERR_SPACE when a symbol does not fit (decode again with out_bytes 4).                              */
+int pcc_range_encode_batch_n(const pcc_cdf_table* t, int32_t n_streams, const void* const* data, int32_t data_bytes,
+                             const void* const* index, int32_t index_bytes, int32_t index_mod, const size_t* n,
+                             uint8_t* const* out, const size_t* cap, size_t* out_len, int32_t n_threads);
+int pcc_range_decode_batch_n(const pcc_cdf_table* t, int32_t n_streams, const uint8_t* const* str, const size_t* str_len,
+                             const void* const* index, int32_t index_bytes, int32_t index_mod, const size_t* n,
+                             void* const* out, int32_t out_bytes, int32_t n_threads);
 /* tfc `pmf_to_quantized_cdf` (src/utils/patch_gaussian_conditional.py:87-89): pmf[n] -> cdf[n+1]. */
 int pcc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, int32_t* cdf);
 

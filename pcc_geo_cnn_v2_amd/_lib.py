@@ -20,7 +20,7 @@ EXPORTS = [
     'pcc_conv_out_dims', 'pcc_conv_mfma_supported', 'pcc_conv_packed_floats', 'pcc_conv_pack_weights',
     'pcc_conv3d', 'pcc_quantize', 'pcc_dequantize', 'pcc_scale_to_index', 'pcc_threshold_compact',
     'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
-    'pcc_range_encode_batch', 'pcc_range_decode_batch', 'pcc_pmf_to_quantized_cdf',
+    'pcc_range_encode_batch', 'pcc_range_decode_batch', 'pcc_range_encode_batch_n', 'pcc_range_decode_batch_n', 'pcc_pmf_to_quantized_cdf',
     'pcc_d1_search_workspace_bytes', 'pcc_d1_threshold_stats', 'pcc_octree_bucket',
     'pcc_network_num_layers', 'pcc_network_layer', 'pcc_weights_blob_floats', 'pcc_weights_pack', 'pcc_weights_upload',
     'pcc_network_workspace_bytes', 'pcc_network_out_dims', 'pcc_network_forward', 'pcc_network_forward_analysis',
@@ -29,6 +29,7 @@ EXPORTS = [
     'pcc_profile_select', 'pcc_profile_read',
 ]
 ABI_VERSION = 2
+PCC_ERR_ARG, PCC_ERR_HIP, PCC_ERR_NOGPU, PCC_ERR_SPACE, PCC_ERR_CORRUPT = -1, -2, -3, -4, -5      # include/pcc_geo.h
 (PCC_NET_ANALYSIS_V1, PCC_NET_SYNTHESIS_V1, PCC_NET_ANALYSIS_V2, PCC_NET_SYNTHESIS_V2, PCC_NET_ANALYSIS_PROGRESSIVE_V2,
  PCC_NET_SYNTHESIS_PROGRESSIVE_V2, PCC_NET_HYPER_ANALYSIS, PCC_NET_HYPER_SYNTHESIS) = range(8)
 

@@ -145,7 +145,8 @@ class Decoder {
     bool corrupt_ = false;
 };
 
-long encode_stream(const pcc_cdf_table& t, const int32_t* data, const int32_t* index, int index_mod, size_t n,
+template <class DataT, class IndexT>
+long encode_stream(const pcc_cdf_table& t, const DataT* data, const IndexT* index, int index_mod, size_t n,
                    uint8_t* out, size_t cap) {
     Encoder e(out, cap);
     const int ow = t.overflow_width;
@@ -153,11 +154,11 @@ long encode_stream(const pcc_cdf_table& t, const int32_t* data, const int32_t* i
     int row_mod = 0;
     for (size_t i = 0; i < n; ++i) {
         int row;
-        if (index) row = index[i];
+        if (index) row = (int)index[i];
         else { row = row_mod; if (++row_mod == index_mod) row_mod = 0; }
         if ((unsigned)row >= (unsigned)t.rows) return -2;
         const int32_t max_value = t.cdf_size[row] - 2;
-        int32_t value = data[i] - t.offset[row];
+        int32_t value = (int32_t)data[i] - t.offset[row];
         uint32_t overflow = 0;
         if (value < 0) { overflow = (uint32_t)(-2 * (int64_t)value - 1); value = max_value; }
         else if (value >= max_value) { overflow = (uint32_t)(2 * ((int64_t)value - max_value)); value = max_value; }
@@ -178,15 +179,17 @@ long encode_stream(const pcc_cdf_table& t, const int32_t* data, const int32_t* i
     return e.overflowed() ? -1 : (long)e.size();
 }
 
-int decode_stream(const pcc_cdf_table& t, const uint8_t* str, size_t len, const int32_t* index, int index_mod,
-                  size_t n, int32_t* out) {
+// returns 0, -1 (corrupt stream), -2 (row out of range), -3 (a symbol does not fit OutT)
+template <class IndexT, class OutT>
+int decode_stream(const pcc_cdf_table& t, const uint8_t* str, size_t len, const IndexT* index, int index_mod,
+                  size_t n, OutT* out) {
     Decoder d(str, len);
     const int ow = t.overflow_width;
     const uint32_t omax = (1u << ow) - 1;
     int row_mod = 0;
     for (size_t i = 0; i < n; ++i) {
         int row;
-        if (index) row = index[i];
+        if (index) row = (int)index[i];
         else { row = row_mod; if (++row_mod == index_mod) row_mod = 0; }
         if ((unsigned)row >= (unsigned)t.rows) return -2;
         const int32_t max_value = t.cdf_size[row] - 2;
@@ -205,7 +208,9 @@ int decode_stream(const pcc_cdf_table& t, const uint8_t* str, size_t len, const 
             if (overflow & 1) value = -value - 1;
             else value += max_value;
         }
-        out[i] = value + t.offset[row];
+        const int32_t sym = value + t.offset[row];
+        out[i] = (OutT)sym;
+        if (sizeof(OutT) < 4 && (int32_t)out[i] != sym) return -3;
     }
     return d.corrupt() ? -1 : 0;
 }
@@ -322,6 +327,65 @@ PCC_API int pcc_range_decode_batch(const pcc_cdf_table* t, int32_t n_streams, co
     });
     if (status.load() != 0) {
         pcc_set_error("pcc_range_decode_batch: %s", status.load() == PCC_ERR_CORRUPT ? "corrupt stream" : "CDF row index out of range");
+        return status.load();
+    }
+    return PCC_OK;
+}
+
+// Narrow host arrays (round 3): symbols as int16 and CDF rows as uint8 -- what crosses PCIe in the codec's hot loop (the Gaussian
+// conditional's 64 scale rows fit a byte; symbols beyond int16 make the caller fall back to the 32-bit entry points).
+PCC_API int pcc_range_encode_batch_n(const pcc_cdf_table* t, int32_t n_streams, const void* const* data, int32_t data_bytes,
+                                     const void* const* index, int32_t index_bytes, int32_t index_mod, const size_t* n,
+                                     uint8_t* const* out, const size_t* cap, size_t* out_len, int32_t n_threads) {
+    if (!table_ok(t) || n_streams < 0 || !data || !n || !out || !cap || !out_len || (data_bytes != 2 && data_bytes != 4) ||
+        (index && index_bytes != 1 && index_bytes != 4)) {
+        pcc_set_error("pcc_range_encode_batch_n: bad argument (data_bytes 2|4, index_bytes 1|4)");
+        return PCC_ERR_ARG;
+    }
+    if (!index && index_mod <= 0) { pcc_set_error("pcc_range_encode_batch_n: index NULL needs index_mod > 0"); return PCC_ERR_ARG; }
+    std::atomic<int> status{0};
+    Pool::get().parallel_for(n_streams, n_threads, [&](int s) {
+        long r;
+        const void* ix = index ? index[s] : nullptr;
+        if (data_bytes == 2) r = (ix && index_bytes == 1) ? encode_stream(*t, (const int16_t*)data[s], (const uint8_t*)ix, index_mod, n[s], out[s], cap[s])
+                                                          : encode_stream(*t, (const int16_t*)data[s], (const int32_t*)ix, index_mod, n[s], out[s], cap[s]);
+        else r = (ix && index_bytes == 1) ? encode_stream(*t, (const int32_t*)data[s], (const uint8_t*)ix, index_mod, n[s], out[s], cap[s])
+                                          : encode_stream(*t, (const int32_t*)data[s], (const int32_t*)ix, index_mod, n[s], out[s], cap[s]);
+        if (r < 0) { status.store(r == -1 ? PCC_ERR_SPACE : PCC_ERR_ARG); out_len[s] = 0; }
+        else out_len[s] = (size_t)r;
+    });
+    if (status.load() != 0) {
+        pcc_set_error("pcc_range_encode_batch_n: %s", status.load() == PCC_ERR_SPACE ? "output buffer too small" : "CDF row index out of range");
+        return status.load();
+    }
+    return PCC_OK;
+}
+
+// out_bytes 2: returns PCC_ERR_SPACE when a decoded symbol does not fit int16 (decode again with out_bytes 4)
+PCC_API int pcc_range_decode_batch_n(const pcc_cdf_table* t, int32_t n_streams, const uint8_t* const* str, const size_t* str_len,
+                                     const void* const* index, int32_t index_bytes, int32_t index_mod, const size_t* n,
+                                     void* const* out, int32_t out_bytes, int32_t n_threads) {
+    if (!table_ok(t) || n_streams < 0 || !str || !str_len || !n || !out || (out_bytes != 2 && out_bytes != 4) ||
+        (index && index_bytes != 1 && index_bytes != 4)) {
+        pcc_set_error("pcc_range_decode_batch_n: bad argument (out_bytes 2|4, index_bytes 1|4)");
+        return PCC_ERR_ARG;
+    }
+    if (!index && index_mod <= 0) { pcc_set_error("pcc_range_decode_batch_n: index NULL needs index_mod > 0"); return PCC_ERR_ARG; }
+    std::atomic<int> status{0};
+    Pool::get().parallel_for(n_streams, n_threads, [&](int s) {
+        int r;
+        const void* ix = index ? index[s] : nullptr;
+        if (out_bytes == 2) r = (ix && index_bytes == 1) ? decode_stream(*t, str[s], str_len[s], (const uint8_t*)ix, index_mod, n[s], (int16_t*)out[s])
+                                                         : decode_stream(*t, str[s], str_len[s], (const int32_t*)ix, index_mod, n[s], (int16_t*)out[s]);
+        else r = (ix && index_bytes == 1) ? decode_stream(*t, str[s], str_len[s], (const uint8_t*)ix, index_mod, n[s], (int32_t*)out[s])
+                                          : decode_stream(*t, str[s], str_len[s], (const int32_t*)ix, index_mod, n[s], (int32_t*)out[s]);
+        if (r == -1) status.store(PCC_ERR_CORRUPT);
+        else if (r == -2) status.store(PCC_ERR_ARG);
+        else if (r == -3) { int z = 0; status.compare_exchange_strong(z, PCC_ERR_SPACE); }
+    });
+    if (status.load() != 0) {
+        pcc_set_error("pcc_range_decode_batch_n: %s", status.load() == PCC_ERR_CORRUPT ? "corrupt stream" :
+                      status.load() == PCC_ERR_SPACE ? "a symbol does not fit the 16-bit output" : "CDF row index out of range");
         return status.load();
     }
     return PCC_OK;

@@ -89,6 +89,11 @@ def select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics, points, r
             for _, m, met in rank_candidates(opt_metrics, cand_metrics, opt_groups)]
 
 
+def _host_dtypes():
+    """(symbol dtype, CDF-row dtype) of the host staging buffers: int16 / uint8; PCC_WIDE_SYMBOLS=1 keeps int32 (A/B runs)."""
+    return (torch.int32, torch.int32) if os.environ.get('PCC_WIDE_SYMBOLS') else (torch.int16, torch.uint8)
+
+
 class _Pinned:
     """Cache of pinned host staging buffers keyed by (tag, shape, dtype)."""
 
@@ -176,7 +181,10 @@ class CompressionModel:
 
     def _copy_out(self, ctx, pairs, ready=None):
         """Device->pinned-host copies (after the permutation into stream order) on a side stream; returns the event the host
-        has to wait for.  `ready`: event after which the sources are final (default: now, on the main stream)."""
+        has to wait for.  `ready`: event after which the sources are final (default: now, on the main stream).
+        pairs: (dst, src) or (dst, src, probe): when dst is narrower than src (int16 symbols / uint8 CDF rows: a third of the
+        PCIe bytes, and of the time the copy kernels hold CUs beside the synthesis) the value is narrowed on the GPU; `probe`
+        (a pinned int32 scalar) then receives max|src| so that the host can tell whether int16 was enough."""
         main = torch.cuda.current_stream(ctx.device)
         if not hasattr(self, '_copy_stream'):
             self._copy_stream = torch.cuda.Stream(ctx.device)
@@ -185,9 +193,14 @@ class CompressionModel:
             ready.record(main)
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(ready)
-            for dst, src in pairs:
+            for item in pairs:
+                dst, src = item[0], item[1]
                 src.record_stream(self._copy_stream)
                 src = self._to_stream_order(src)
+                if dst.dtype != src.dtype:
+                    if len(item) > 2 and item[2] is not None:
+                        item[2].copy_(src.abs().amax().reshape(1), non_blocking=True)
+                    src = src.to(dst.dtype)
                 dst.copy_(src, non_blocking=True)
                 src.record_stream(self._copy_stream)
             done = torch.cuda.Event()
@@ -279,6 +292,21 @@ class CompressionModel:
             self._codec_cache = (key, ops.codec_desc(ctx, 2 if v2 else 1, self.num_filters, nets, med, tab, self.round_mode),
                                  list(nets.values()))
         return self._codec_cache[1][0]
+
+    def _decode_symbols(self, ctx, table, strings, n, index_list, index_mod, sym_h, release):
+        """Range-decodes one stream per block into the int16 pinned buffer `sym_h` (B, ...), moves it to the GPU (half the PCIe
+        bytes of int32) and returns the int32 (B,D,H,W,C) device tensor.  A symbol beyond int16 (OverflowError from the coder:
+        never seen in practice) repeats the decode into int32."""
+        B = len(strings)
+        try:
+            ops.range_decode_batch(table, strings, [n] * B, index_list, index_mod, self.coder_threads,
+                                   out=[sym_h[b].numpy().reshape(-1) for b in range(B)])
+            dev = sym_h.to(ctx.device, non_blocking=True)
+            release(torch.cuda.current_stream(ctx.device))
+        except OverflowError:
+            wide = ops.range_decode_batch(table, strings, [n] * B, index_list, index_mod, self.coder_threads)
+            dev = torch.from_numpy(np.stack(wide).reshape(sym_h.shape)).to(ctx.device)
+        return self._from_stream_order(dev.to(torch.int32))
 
     def _gather_points(self, xyz, counts, ctx=None, ready=None):
         """Point lists to the host.  When `ready` (an event recorded after the compaction kernels) is given, the
@@ -824,12 +852,16 @@ class CompressionModelV2(CompressionModel):
             sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
             idx = ops.scale_to_index(ctx, sigma, tab)
             ysym, y_hat = ops.quantize(ctx, y, None, self.round_mode)
-        zsym_h = self._pinned.get(('zsym', slot), self._stream_shape(B, zsym.shape[1:4], F), torch.int32)
-        ysym_h = self._pinned.get(('ysym', slot), self._stream_shape(B, ysym.shape[1:4], F), torch.int32)
-        idx_h = self._pinned.get(('idx', slot), self._stream_shape(B, idx.shape[1:4], F), torch.int32)
+        # what crosses PCIe: symbols as int16, the 64 scale rows as uint8 (8.5 -> 3.3 MB per 32-block chunk); `probe` tells the
+        # host afterwards whether a symbol exceeded int16 (then that tensor is fetched again as int32: never seen in practice)
+        sym_t, row_t = _host_dtypes()
+        zsym_h = self._pinned.get(('zsym', slot), self._stream_shape(B, zsym.shape[1:4], F), sym_t)
+        ysym_h = self._pinned.get(('ysym', slot), self._stream_shape(B, ysym.shape[1:4], F), sym_t)
+        idx_h = self._pinned.get(('idx', slot), self._stream_shape(B, idx.shape[1:4], F), row_t)
+        probe = self._pinned.get(('probe', slot), (2,), torch.int32)
         # symbols leave on a side stream (permutation into stream order + copy) so that they overlap the synthesis transform:
         # `ready` is recorded by the library between the last quantiser and the first synthesis layer
-        ev = self._copy_out(ctx, [(zsym_h, zsym), (ysym_h, ysym), (idx_h, idx)], ready)
+        ev = self._copy_out(ctx, [(zsym_h, zsym, probe[0:1]), (ysym_h, ysym, probe[1:2]), (idx_h, idx)], ready)
         if codec is None:
             x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
             if thr is not None:
@@ -838,9 +870,12 @@ class CompressionModelV2(CompressionModel):
 
         def finish():
             ev.synchronize()  # symbols are on the host
-            zs = ops.range_encode_batch(eb.table, [zsym_h[b] for b in range(B)], None if rows is None else [rows] * B, mod,
+            fits = sym_t == torch.int32
+            zs_src = zsym_h if fits or int(probe[0]) <= 32767 else self._to_stream_order(zsym).cpu()
+            ys_src = ysym_h if fits or int(probe[1]) <= 32767 else self._to_stream_order(ysym).cpu()
+            zs = ops.range_encode_batch(eb.table, [zs_src[b] for b in range(B)], None if rows is None else [rows] * B, mod,
                                         self.coder_threads)
-            ys = ops.range_encode_batch(gc.table, [ysym_h[b] for b in range(B)], [idx_h[b] for b in range(B)], 0,
+            ys = ops.range_encode_batch(gc.table, [ys_src[b] for b in range(B)], [idx_h[b] for b in range(B)], 0,
                                         self.coder_threads)
             return list(zip(ys, zs))  # strings = (y_string, z_string), model_types.py:389
 
@@ -858,13 +893,10 @@ class CompressionModelV2(CompressionModel):
         eb, gc = self.entropy_bottleneck, self.conditional_bottleneck
         zshape = self._stream_shape(B, [v // 16 for v in dhw], F)
         # per-slot cached pinned buffers (like the encoder's): nothing is allocated in the steady state
-        zsym_h, zsym_release = self._pinned.ring('dec_zsym', zshape, torch.int32)
+        zsym_h, zsym_release = self._pinned.ring('dec_zsym', zshape, _host_dtypes()[0])
         nz = int(np.prod(zshape[1:]))
         rows, mod = self._eb_rows(nz, F)
-        ops.range_decode_batch(eb.table, [s[1] for s in strings], [nz] * B, None if rows is None else [rows] * B, mod,
-                               self.coder_threads, out=[zsym_h[b].numpy() for b in range(B)])
-        zsym = self._from_stream_order(zsym_h.to(ctx.device, non_blocking=True))
-        zsym_release(torch.cuda.current_stream(ctx.device))
+        zsym = self._decode_symbols(ctx, eb.table, [s[1] for s in strings], nz, None if rows is None else [rows] * B, mod, zsym_h, zsym_release)
         codec = self._codec(ctx)
         if codec is not None:                      # dequantise z -> hyper-synthesis -> indexes in one ABI call
             t = ops.codec_decode_hyper(ctx, codec, zsym, dhw)
@@ -873,9 +905,9 @@ class CompressionModelV2(CompressionModel):
             z_hat = ops.dequantize(ctx, zsym, self._dev(ctx, 'medians', eb.medians))
             sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
             idx = ops.scale_to_index(ctx, sigma, self._dev(ctx, 'scale_table', gc.scale_table_f32))
-        idx_s = self._to_stream_order(idx)
+        idx_s = self._to_stream_order(idx).to(_host_dtypes()[1])      # 64 scale rows: one byte each over PCIe
         # (the host reads idx_h synchronously in phase b, long before the ring comes round: no release event needed)
-        idx_h, _ = self._pinned.ring('dec_idx', idx_s.shape, torch.int32)
+        idx_h, _ = self._pinned.ring('dec_idx', idx_s.shape, _host_dtypes()[1])
         idx_h.copy_(idx_s, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(ctx.device))
@@ -887,12 +919,9 @@ class CompressionModelV2(CompressionModel):
         strings, idx_h = st['strings'], st['idx_h']
         B = len(strings)
         st['ev'].synchronize()
-        ysym_h, ysym_release = self._pinned.ring('dec_ysym', idx_h.shape, torch.int32)
+        ysym_h, ysym_release = self._pinned.ring('dec_ysym', idx_h.shape, _host_dtypes()[0])
         n = int(np.prod(idx_h.shape[1:]))
-        ops.range_decode_batch(gc.table, [s[0] for s in strings], [n] * B, [idx_h[b] for b in range(B)], 0,
-                               self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
-        ysym = self._from_stream_order(ysym_h.to(ctx.device, non_blocking=True))
-        ysym_release(torch.cuda.current_stream(ctx.device))
+        ysym = self._decode_symbols(ctx, gc.table, [s[0] for s in strings], n, [idx_h[b] for b in range(B)], 0, ysym_h, ysym_release)
         codec = self._codec(ctx)
         if codec is not None:                      # dequantise -> synthesis (-> threshold + compaction) in one ABI call
             t = ops.codec_decode_main(ctx, codec, ysym, dhw, thr)

@@ -454,13 +454,32 @@ def _np_i32(a):
     return a
 
 
+def _np_host(a, allowed):
+    """flat contiguous host array; keeps a dtype in `allowed` (narrow staging buffers), anything else becomes int32"""
+    if isinstance(a, torch.Tensor):
+        a = a.numpy()
+    a = np.asarray(a)
+    return np.ascontiguousarray(a if a.dtype in allowed else a.astype(np.int32)).reshape(-1)
+
+
+def _uniform_dtype(arrs, allowed):
+    """one dtype for all streams of a call (the ABI takes one element size per call)"""
+    if all(a.dtype == arrs[0].dtype for a in arrs) and arrs[0].dtype in allowed:
+        return arrs, arrs[0].dtype.itemsize
+    return [np.ascontiguousarray(a, np.int32) for a in arrs], 4
+
+
+_SYM, _ROW = (np.dtype(np.int16), np.dtype(np.int32)), (np.dtype(np.uint8), np.dtype(np.int32))
+
+
 def range_encode_batch(table, data_list, index_list=None, index_mod=0, n_threads=0):
-    """data_list: per-stream int32 arrays (numpy or CPU torch).  Returns list of bytes."""
+    """data_list: per-stream symbol arrays, int32 or int16; index_list: per-stream CDF rows, int32 or uint8 (numpy or CPU
+    torch).  Returns list of bytes."""
     S = len(data_list)
     if S == 0:
         return []
-    data = [_np_i32(d) for d in data_list]
-    idx = None if index_list is None else [_np_i32(i) for i in index_list]
+    data, db = _uniform_dtype([_np_host(d, _SYM) for d in data_list], _SYM)
+    idx, ib = (None, 4) if index_list is None else _uniform_dtype([_np_host(i, _ROW) for i in index_list], _ROW)
     n = (C.c_size_t * S)(*[d.size for d in data])
     caps = [d.size * 8 + 64 for d in data]
     outs = [np.empty(c, np.uint8) for c in caps]
@@ -469,27 +488,40 @@ def range_encode_batch(table, data_list, index_list=None, index_mod=0, n_threads
     op = (C.c_void_p * S)(*[o.ctypes.data for o in outs])
     cap = (C.c_size_t * S)(*caps)
     olen = (C.c_size_t * S)()
-    L.check(L.lib().pcc_range_encode_batch(C.byref(table.struct), S, dp, ip, index_mod, n, op, cap, olen, n_threads),
-            'pcc_range_encode_batch')
+    if db == 4 and ib == 4:
+        L.check(L.lib().pcc_range_encode_batch(C.byref(table.struct), S, dp, ip, index_mod, n, op, cap, olen, n_threads),
+                'pcc_range_encode_batch')
+    else:
+        L.check(L.lib().pcc_range_encode_batch_n(C.byref(table.struct), S, dp, db, ip, ib, index_mod, n, op, cap, olen, n_threads),
+                'pcc_range_encode_batch_n')
     return [outs[s][:olen[s]].tobytes() for s in range(S)]
 
 
 def range_decode_batch(table, strings, n_list, index_list=None, index_mod=0, n_threads=0, out=None):
-    """strings: list of bytes; n_list: symbols per stream.  Returns list of int32 numpy arrays (or
-    fills the provided `out` arrays)."""
+    """strings: list of bytes; n_list: symbols per stream; index_list: int32 or uint8 CDF rows.  Returns list of int32 numpy
+    arrays, or fills the provided `out` arrays (int32, or int16: then a symbol that does not fit raises OverflowError and the
+    caller decodes into int32)."""
     S = len(strings)
     if S == 0:
         return []
     bufs = [np.frombuffer(s, np.uint8) if len(s) else np.zeros(1, np.uint8) for s in strings]
-    idx = None if index_list is None else [_np_i32(i) for i in index_list]
+    idx, ib = (None, 4) if index_list is None else _uniform_dtype([_np_host(i, _ROW) for i in index_list], _ROW)
     outs = [np.empty(int(k), np.int32) for k in n_list] if out is None else out
+    ob = outs[0].dtype.itemsize
+    assert all(o.dtype == outs[0].dtype and o.flags['C_CONTIGUOUS'] for o in outs) and outs[0].dtype in _SYM
     sp = (C.c_void_p * S)(*[b.ctypes.data for b in bufs])
     sl = (C.c_size_t * S)(*[len(s) for s in strings])
     ip = None if idx is None else (C.c_void_p * S)(*[i.ctypes.data for i in idx])
     n = (C.c_size_t * S)(*[int(k) for k in n_list])
     op = (C.c_void_p * S)(*[o.ctypes.data for o in outs])
-    L.check(L.lib().pcc_range_decode_batch(C.byref(table.struct), S, sp, sl, ip, index_mod, n, op, n_threads),
-            'pcc_range_decode_batch')
+    if ob == 4 and ib == 4:
+        L.check(L.lib().pcc_range_decode_batch(C.byref(table.struct), S, sp, sl, ip, index_mod, n, op, n_threads),
+                'pcc_range_decode_batch')
+    else:
+        rc = L.lib().pcc_range_decode_batch_n(C.byref(table.struct), S, sp, sl, ip, ib, index_mod, n, op, ob, n_threads)
+        if rc == L.PCC_ERR_SPACE and ob == 2:
+            raise OverflowError('a decoded symbol does not fit int16')
+        L.check(rc, 'pcc_range_decode_batch_n')
     return outs
 
 

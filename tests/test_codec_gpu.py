@@ -172,6 +172,30 @@ def test_compress_decompress_blocks_roundtrip(ctx, name, res, nb, precision):
     assert total > 0, 'degenerate test: no decoded points at the fixed threshold'
 
 
+def test_symbols_beyond_int16_take_the_wide_path(ctx):
+    """The codec moves symbols as int16 and scale rows as uint8 across PCIe (round 3).  Symbols that do not fit -- provoked here
+    with absurdly scaled analysis weights -- must take the int32 fallback on both sides: encoder probe, decoder OverflowError."""
+    res = 16
+    enc = ModelConfigType['c3p'].build(batch_size=2)
+    enc.compress([1, 1, res, res, res])
+    w = scaled_weights(enc, 2.2)
+    last = max(int(k.split('/')[1]) for k in w if k.startswith('analysis/'))
+    w[f'analysis/{last}/kernel'] = (w[f'analysis/{last}/kernel'] * 3e4).astype(np.float32)
+    enc.set_weights(w)
+    x = (torch.rand((2, res, res, res), generator=torch.Generator().manual_seed(4)) < 0.1).float().to(ctx.device)
+    e = enc._encode_batch(enc._ctx(ctx), x, debug=True)
+    strings = e['finish']()
+    assert max(np.abs(d['symbols']).max() for d in e['debug']) > 40000
+    dec = ModelConfigType['c3p'].build(batch_size=2)
+    dec.decompress()
+    dec.set_weights({k: v for k, v in w.items() if not k.startswith(('analysis/', 'hyper_analysis/'))})
+    _, dbg = dec.decompress_blocks(ctx, [(s, 128) for s in strings], [res] * 3, debug=True)
+    for b in range(2):
+        assert np.array_equal(e['debug'][b]['symbols'], dbg[b]['symbols'])
+        assert np.array_equal(e['debug'][b]['indexes'], dbg[b]['indexes'])
+        assert np.array_equal(e['debug'][b]['x_hat'], dbg[b]['x_hat'])
+
+
 def test_adaptive_threshold_path(ctx):
     res = 16
     from pcc_geo_cnn_v2_amd.utils.octree_coding import partition_octree

@@ -169,6 +169,39 @@ def test_host_search_pool_survives_a_dead_worker():
         pool.close()
 
 
+def test_range_coder_on_narrow_host_arrays():
+    """pcc_range_encode_batch_n / pcc_range_decode_batch_n: int16 symbols and uint8 CDF rows (what the codec moves across PCIe) give
+    the bytes / symbols of the int32 entry points; a symbol beyond int16 is reported (OverflowError) instead of wrapped."""
+    from pcc_geo_cnn_v2_amd import ops
+    from pcc_geo_cnn_v2_amd.entropy_models import EntropyBottleneck, GaussianConditional, scale_table
+    gc = GaussianConditional(scale_table(0.11, 256, 64))
+    rng = np.random.default_rng(0)
+    idx = [rng.integers(0, 64, 5000).astype(np.int32) for _ in range(3)]
+    sym = [np.round(rng.normal(0, 1 + 20 * k, 5000)).astype(np.int32) for k in range(3)]
+    sym[2][[7, 4999]] = [-3000, 32767]                      # overflow symbols of the coder (beyond the table), still int16
+    ref = ops.range_encode_batch(gc.table, sym, idx, 0, 2)
+    got = ops.range_encode_batch(gc.table, [s.astype(np.int16) for s in sym], [i.astype(np.uint8) for i in idx], 0, 2)
+    assert got == ref
+    assert ops.range_encode_batch(gc.table, [s.astype(np.int16) for s in sym], idx, 0, 2) == ref          # int16 symbols, int32 rows
+    out = [np.empty(5000, np.int16) for _ in range(3)]
+    ops.range_decode_batch(gc.table, ref, [5000] * 3, [i.astype(np.uint8) for i in idx], 0, 2, out=out)
+    assert all(np.array_equal(o, s) for o, s in zip(out, sym))
+    # row = position modulo (factorized prior, channels_last): no index arrays at all
+    eb = EntropyBottleneck(8, seed=1)
+    zs = [np.round(rng.normal(0, 2, 800)).astype(np.int32) for _ in range(2)]
+    assert ops.range_encode_batch(eb.table, [z.astype(np.int16) for z in zs], None, 8, 1) == ops.range_encode_batch(eb.table, zs, None, 8, 1)
+    # a symbol that does not fit int16
+    big = [s.copy() for s in sym]
+    big[1][100] = 40000
+    wide = ops.range_encode_batch(gc.table, big, idx, 0, 2)
+    with pytest.raises(OverflowError):
+        ops.range_decode_batch(gc.table, wide, [5000] * 3, [i.astype(np.uint8) for i in idx], 0, 2, out=out)
+    dec = ops.range_decode_batch(gc.table, wide, [5000] * 3, [i.astype(np.uint8) for i in idx], 0, 2)
+    assert all(np.array_equal(o, s) and o.dtype == np.int32 for o, s in zip(dec, big))
+    # mixed dtypes in one call fall back to the 32-bit entry point
+    assert ops.range_encode_batch(gc.table, [big[0].astype(np.int16), big[1], big[2].astype(np.int16)], idx, 0, 2) == wide
+
+
 # ---------------------------------------------------------------- not a transcription of the reference's Python
 REF = '/root/reference/src'
 PAIRS = [('pcc_geo_cnn_v2_amd/utils/pc_metric.py', 'utils/pc_metric.py'), ('pcc_geo_cnn_v2_amd/model_opt.py', 'model_opt.py'),
