@@ -40,14 +40,14 @@ def c3p_step_flops(res, batch, num_cu=256, winograd=True):
     """(algorithmic, executed) fp32 MFMA flops of ONE block through compress graph + decompress graph of c3p (the unit of
     SURVEY.md 8d): algorithmic = direct convolution, 2 * MACs as the reference executes them; executed = what the kernels
     issue: the k3 stride-1 layers that csrc/conv_wino.hip takes (conv_mfma.hip dispatch rule: Cin = Cout in {16, 32, 64}, H and W
-    multiples of 16, 32-channel layers only from 32^3 up) run 16 instead of 36 multiplies per 2x2 outputs and z tap and march
+    multiples of 16) run 16 instead of 36 multiplies per 2x2 outputs and z tap and march
     zlen + 2 input planes per zlen outputs, the first of them with a third of its MFMA rows (zlen = D / z-split, the split that
     gives every CU a workgroup)."""
     def wino_factor(ch, d):
-        if not winograd or d % 16 or (ch == 32 and d < 32):
+        if not winograd or d % 16:
             return 1.0
         zs, base = 1, batch * (d // 16) ** 2 * (ch // 16)
-        while base * zs < num_cu and d % (zs * 2) == 0 and d // (zs * 2) >= 8:
+        while base * zs < num_cu and d % (zs * 2) == 0 and d // (zs * 2) >= (4 if ch >= 32 else 8):
             zs *= 2
         zlen = d // zs
         return 16.0 / 36.0 * (zlen + 1 + 1.0 / 3.0) / zlen      # + a full tail plane + the dz-0 rows of the head plane

@@ -1750,7 +1750,7 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
             static const bool no_wino = getenv("PCC_NO_WINOGRAD") != nullptr;
             static const bool no_wino32 = getenv("PCC_NO_WINOGRAD32") != nullptr;
             static const bool wino64 = getenv("PCC_NO_WINOGRAD64") == nullptr;
-            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !(d->flags & PCC_CONV_F16) && !no_wino && !(ci == 32 && (no_wino32 || d->D < 32)) && !(ci == 64 && !wino64));
+            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !(d->flags & PCC_CONV_F16) && !no_wino && !(ci == 32 && (no_wino32 || d->D < 16)) && !(ci == 64 && !wino64));
             if (want && pcc_wino_eligible(d)) return pcc_conv_wino(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, residual, out, st);
             PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD needs W and H multiples of 16");
         } else {
