@@ -298,6 +298,8 @@ def main():
     t0 = time.perf_counter()
     n_blocks, n_bytes, n_pts = run(args.steps)
     barrier()
+    if os.environ.get('PCC_BENCH_STAMPS'):      # arrival spacing of the chunks (ms), for pipeline debugging
+        print('stamps', ' '.join(f'{1e3 * (b - a):.2f}' for a, b in zip(stamps[:-1], stamps[1:])), file=sys.stderr)
     t1 = time.perf_counter()
     elapsed = t1 - t0
     steady_ms = steady_ms_per_step(BATCH // args.chunk)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PCC_ABI_VERSION 2
+#define PCC_ABI_VERSION 3
 
 /* ---- errors / context ------------------------------------------------------------------ */
 #define PCC_OK 0
@@ -179,20 +179,39 @@ size_t pcc_codec_workspace_bytes(const pcc_codec_desc* c, int32_t N, int32_t D, 
  * thr, xyz, counts, cap, scratch as in pcc_threshold_compact with clip = 1.  symbols_ready: NULL or a hipEvent_t the
  * library records on `stream` as soon as zsym / idx / ysym are final, i.e. BEFORE the synthesis transform is enqueued, so
  * that the device->host copy and the host range coder overlap the synthesis.                                               */
+/* io (may be NULL): the symbols on their way to / from the host coder, in the coder's stream order and integer width.
+ * Encoder: before `symbols_ready` is recorded the library packs zsym, ysym and idx into the caller's device staging buffers
+ * (pcc_symbols_pack), so that ONE device->host copy on the caller's side stream is all that runs beside the synthesis
+ * transform (round 2 ran the permutation, the narrowing and a max-reduction there as separate kernels, which compete with the
+ * one-workgroup-per-CU convolution kernels for CUs).  Decoder: io->zsym / io->ysym are the INPUT of pcc_codec_decode_hyper /
+ * _main (what the host->device copy delivered; the library unpacks it into the int32 `zsym` / `ysym` argument, which is then
+ * an output), io->idx receives the packed indexes of pcc_codec_decode_hyper.  Pointers of tensors a call does not touch may be
+ * NULL.                                                                                                                    */
+typedef struct {
+    void* zsym;               /* device, stream order, sym_bytes per element (V2)                                       */
+    void* ysym;
+    void* idx;                /* device, stream order, idx_bytes per element (V2)                                       */
+    int32_t* zsym_tile_max;   /* device int32[pcc_symbols_tiles(N, vox_z, F)]: max|symbol| per packed tile; may be NULL  */
+    int32_t* ysym_tile_max;   /* device int32[pcc_symbols_tiles(N, vox_y, F)]                                           */
+    int32_t sym_bytes;        /* 2 or 4                                                                                 */
+    int32_t idx_bytes;        /* 1 or 4                                                                                 */
+    int32_t channels_first;   /* stream order: 1 = (C, D,H,W) per block (the reference's default), 0 = (D,H,W, C)       */
+} pcc_symbol_io;
 int pcc_codec_encode(pcc_ctx* ctx, const pcc_codec_desc* c, const float* x, int32_t N, int32_t D, int32_t H, int32_t W,
                      float* y, float* z, int32_t* zsym, float* z_hat, float* sigma, int32_t* idx, int32_t* ysym,
                      float* y_hat, float* x_hat, const float* thr, float* xyz, int32_t* counts, int64_t cap,
                      int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags, int32_t final_flags,
-                     void* symbols_ready, void* stream);
+                     const pcc_symbol_io* sink, void* symbols_ready, void* stream);
 /* decompress graph, V2 first phase (model_types.py:403-406): zsym -> z_hat -> sigma -> idx.                               */
-int pcc_codec_decode_hyper(pcc_ctx* ctx, const pcc_codec_desc* c, const int32_t* zsym, int32_t N, int32_t D, int32_t H,
+int pcc_codec_decode_hyper(pcc_ctx* ctx, const pcc_codec_desc* c, int32_t* zsym, int32_t N, int32_t D, int32_t H,
                            int32_t W, float* z_hat, float* sigma, int32_t* idx, void* workspace, size_t workspace_bytes,
-                           int32_t layer_flags, void* stream);
+                           int32_t layer_flags, const pcc_symbol_io* io, void* stream);
 /* decompress graph, main phase (:305-307 / :407-408): ysym -> y_hat -> x_hat and, when thr != NULL, the unclipped
  * thresholding + compaction of :232-234 (arguments as pcc_threshold_compact).                                              */
-int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, const int32_t* ysym, int32_t N, int32_t D, int32_t H,
+int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, int32_t* ysym, int32_t N, int32_t D, int32_t H,
                           int32_t W, float* y_hat, float* x_hat, const float* thr, float* xyz, int32_t* counts, int64_t cap,
-                          int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags, void* stream);
+                          int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags,
+                          const pcc_symbol_io* io, void* stream);
 
 /* Live kernel timing: HIP events recorded on the launch stream around layer `layer` of transform `transform` in every
  * pcc_network_forward / pcc_codec_* call (transform < 0 switches it off); pcc_profile_read waits for the recorded events,
@@ -216,6 +235,18 @@ int pcc_dequantize(pcc_ctx* ctx, const int32_t* sym, const float* medians, float
  * lower-bounded at table[0]; idx = (L-1) - #{j < L-1 : sigma <= table[j]}.  Deterministic. */
 int pcc_scale_to_index(pcc_ctx* ctx, const float* sigma, const float* table, int32_t L,
                        int32_t* idx, size_t n, void* stream);
+
+/* ---- symbols / CDF-row indexes between the device tensors and the host coder -------------
+ * tfc 1.3 codes each block's tensor flattened in ITS memory order (src/model_types.py:180,254,377: data_format
+ * 'channels_first' -> (C, D,H,W), channel-major streams); the device tensors are NDHWC int32.  pcc_symbols_pack writes N
+ * blocks of (vox, C) int32 in stream order as dst_bytes-wide integers (1: uint8, 2: int16, 4: int32; values are truncated --
+ * tile_max, when given, receives max|value| of every 64 x 64 tile (pcc_symbols_tiles entries) so that the host can tell
+ * whether the narrow type was enough); pcc_symbols_unpack is the inverse (decoder side).  HBM-bound byte work.            */
+size_t pcc_symbols_tiles(int32_t N, int64_t vox, int32_t C);
+int pcc_symbols_pack(pcc_ctx* ctx, const int32_t* src, int32_t N, int64_t vox, int32_t C, int32_t channels_first,
+                     void* dst, int32_t dst_bytes, int32_t* tile_max, void* stream);
+int pcc_symbols_unpack(pcc_ctx* ctx, const void* src, int32_t src_bytes, int32_t N, int64_t vox, int32_t C,
+                       int32_t channels_first, int32_t* dst, void* stream);
 
 /* ---- occupancy thresholding + order-preserving compaction ------------------------------
  * Replaces `np.argwhere(x_hat > thresholds[t]).astype(float32)` (src/model_types.py:209,233-234,

@@ -20,6 +20,7 @@ EXPORTS = [
     'pcc_conv_out_dims', 'pcc_conv_mfma_supported', 'pcc_conv_packed_floats', 'pcc_conv_pack_weights',
     'pcc_conv3d', 'pcc_quantize', 'pcc_dequantize', 'pcc_scale_to_index', 'pcc_threshold_compact',
     'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
+    'pcc_symbols_tiles', 'pcc_symbols_pack', 'pcc_symbols_unpack',
     'pcc_range_encode_batch', 'pcc_range_decode_batch', 'pcc_range_encode_batch_n', 'pcc_range_decode_batch_n', 'pcc_pmf_to_quantized_cdf',
     'pcc_d1_search_workspace_bytes', 'pcc_d1_threshold_stats', 'pcc_octree_bucket',
     'pcc_network_num_layers', 'pcc_network_layer', 'pcc_weights_blob_floats', 'pcc_weights_pack', 'pcc_weights_upload',
@@ -28,7 +29,7 @@ EXPORTS = [
     'pcc_codec_workspace_bytes', 'pcc_codec_encode', 'pcc_codec_decode_hyper', 'pcc_codec_decode_main',
     'pcc_profile_select', 'pcc_profile_read',
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 PCC_ERR_ARG, PCC_ERR_HIP, PCC_ERR_NOGPU, PCC_ERR_SPACE, PCC_ERR_CORRUPT = -1, -2, -3, -4, -5      # include/pcc_geo.h
 (PCC_NET_ANALYSIS_V1, PCC_NET_SYNTHESIS_V1, PCC_NET_ANALYSIS_V2, PCC_NET_SYNTHESIS_V2, PCC_NET_ANALYSIS_PROGRESSIVE_V2,
  PCC_NET_SYNTHESIS_PROGRESSIVE_V2, PCC_NET_HYPER_ANALYSIS, PCC_NET_HYPER_SYNTHESIS) = range(8)
@@ -50,6 +51,11 @@ class CodecDesc(C.Structure):
                 ('w_analysis', C.c_void_p), ('w_synthesis', C.c_void_p), ('w_hyper_analysis', C.c_void_p),
                 ('w_hyper_synthesis', C.c_void_p), ('medians', C.c_void_p), ('scale_table', C.c_void_p),
                 ('scale_levels', C.c_int32), ('round_mode', C.c_int32)]
+
+
+class SymbolSink(C.Structure):
+    _fields_ = [('zsym', C.c_void_p), ('ysym', C.c_void_p), ('idx', C.c_void_p), ('zsym_tile_max', C.c_void_p),
+                ('ysym_tile_max', C.c_void_p), ('sym_bytes', C.c_int32), ('idx_bytes', C.c_int32), ('channels_first', C.c_int32)]
 
 
 class PccError(RuntimeError):
@@ -116,10 +122,14 @@ def lib():
     L.pcc_codec_workspace_bytes.argtypes = [C.POINTER(CodecDesc), i32, i32, i32, i32]
     L.pcc_codec_workspace_bytes.restype = sz
     L.pcc_codec_encode.argtypes = [vp, C.POINTER(CodecDesc), vp, i32, i32, i32, i32] + [vp] * 9 + [vp, vp, vp, C.c_int64, vp] + \
-        [vp, sz, i32, i32, vp, vp]
-    L.pcc_codec_decode_hyper.argtypes = [vp, C.POINTER(CodecDesc), vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, i32, vp]
+        [vp, sz, i32, i32, C.POINTER(SymbolSink), vp, vp]
+    L.pcc_symbols_tiles.argtypes = [i32, C.c_int64, i32]
+    L.pcc_symbols_tiles.restype = sz
+    L.pcc_symbols_pack.argtypes = [vp, vp, i32, C.c_int64, i32, i32, vp, i32, vp, vp]
+    L.pcc_symbols_unpack.argtypes = [vp, vp, i32, i32, C.c_int64, i32, i32, vp, vp]
+    L.pcc_codec_decode_hyper.argtypes = [vp, C.POINTER(CodecDesc), vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, i32, C.POINTER(SymbolSink), vp]
     L.pcc_codec_decode_main.argtypes = [vp, C.POINTER(CodecDesc), vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, C.c_int64, vp,
-                                        vp, sz, i32, vp]
+                                        vp, sz, i32, C.POINTER(SymbolSink), vp]
     L.pcc_profile_select.argtypes = [vp, i32, i32]
     L.pcc_profile_read.argtypes = [vp, vp, i32, C.POINTER(i32)]
     for name in EXPORTS:

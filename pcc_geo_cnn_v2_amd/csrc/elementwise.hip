@@ -56,6 +56,146 @@ __global__ void __launch_bounds__(kThreads) k_scale_index(const float* __restric
     }
 }
 
+// ---- symbols / CDF-row indexes <-> the host coder's stream order ------------------------------------------------------------
+// The range-coded streams of one block are its tensor flattened in the reference's memory order (model_types.py:180,254,377:
+// data_format 'channels_first' -> (C, D,H,W), channel-major); on the device everything is NDHWC int32.  These two kernels are the
+// only thing between the quantisers and the PCIe copy: a 64-voxel x 64-channel tile goes through LDS (coalesced on both sides),
+// the value is narrowed (int16 symbols, uint8 CDF rows: a third of the PCIe bytes) and every tile reports max|value| as a plain
+// store (no atomics, nothing to zero) so that the host can tell afterwards whether the narrow type was enough.
+constexpr int kPackT = 64;
+
+template <typename T>
+__device__ __forceinline__ T narrow(int32_t v) { return (T)v; }
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) PackVec { T v[N]; };
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_symbols_pack(const int32_t* __restrict__ src, T* __restrict__ dst, int vox, int C,
+                                                            int vtiles, int ctiles, int channels_first,
+                                                            int32_t* __restrict__ tile_max) {
+    __shared__ int32_t tile[kPackT][kPackT + 1];
+    __shared__ int32_t wmax[kThreads / 64];
+    int t = blockIdx.x;
+    const int ct = t % ctiles; t /= ctiles;
+    const int vt = t % vtiles;
+    const int n = t / vtiles;
+    const int v0 = vt * kPackT, c0 = ct * kPackT;
+    const int nv = min(kPackT, vox - v0), nc = min(kPackT, C - c0);
+    const int32_t* sb = src + ((size_t)n * vox + v0) * C + c0;
+    int32_t m = 0;
+    const bool full = nv == kPackT && nc == kPackT && (C & 3) == 0 && (vox & 3) == 0;     // whole, 16-byte aligned tile
+    if (channels_first && full) {
+        // four 16-byte loads per thread in flight, then LDS; four consecutive voxels per store on the way out
+        int4 x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * kThreads, v = i >> 4, q = i & 15;
+            x[k] = *reinterpret_cast<const int4*>(sb + (size_t)v * C + q * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * kThreads, v = i >> 4, q = i & 15;
+            tile[q * 4 + 0][v] = x[k].x; tile[q * 4 + 1][v] = x[k].y; tile[q * 4 + 2][v] = x[k].z; tile[q * 4 + 3][v] = x[k].w;
+            m = max(max(m, abs(x[k].x)), max(max(abs(x[k].y), abs(x[k].z)), abs(x[k].w)));
+        }
+        __syncthreads();
+        T* db = dst + ((size_t)n * C + c0) * vox + v0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * kThreads, c = i >> 4, vq = i & 15;
+            PackVec<T, 4> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.v[e] = narrow<T>(tile[c][vq * 4 + e]);
+            *reinterpret_cast<PackVec<T, 4>*>(db + (size_t)c * vox + vq * 4) = o;
+        }
+    } else if (channels_first) {
+        for (int i = threadIdx.x; i < nv * kPackT; i += kThreads) {
+            const int v = i / kPackT, c = i % kPackT;
+            if (c < nc) {
+                const int32_t x = sb[(size_t)v * C + c];
+                tile[c][v] = x;
+                m = max(m, abs(x));
+            }
+        }
+        __syncthreads();
+        T* db = dst + ((size_t)n * C + c0) * vox + v0;
+        for (int i = threadIdx.x; i < nc * kPackT; i += kThreads) {
+            const int c = i / kPackT, v = i % kPackT;
+            if (v < nv) db[(size_t)c * vox + v] = narrow<T>(tile[c][v]);
+        }
+    } else {
+        T* db = dst + ((size_t)n * vox + v0) * C + c0;
+        for (int i = threadIdx.x; i < nv * kPackT; i += kThreads) {
+            const int v = i / kPackT, c = i % kPackT;
+            if (c < nc) {
+                const int32_t x = sb[(size_t)v * C + c];
+                db[(size_t)v * C + c] = narrow<T>(x);
+                m = max(m, abs(x));
+            }
+        }
+    }
+    if (tile_max) {
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_max[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) k_symbols_unpack(const T* __restrict__ src, int32_t* __restrict__ dst, int vox, int C,
+                                                              int vtiles, int ctiles, int channels_first) {
+    __shared__ int32_t tile[kPackT][kPackT + 1];
+    int t = blockIdx.x;
+    const int ct = t % ctiles; t /= ctiles;
+    const int vt = t % vtiles;
+    const int n = t / vtiles;
+    const int v0 = vt * kPackT, c0 = ct * kPackT;
+    const int nv = min(kPackT, vox - v0), nc = min(kPackT, C - c0);
+    int32_t* db = dst + ((size_t)n * vox + v0) * C + c0;
+    const bool full = nv == kPackT && nc == kPackT && (C & 3) == 0 && (vox & 3) == 0;
+    if (channels_first && full) {
+        const T* sb = src + ((size_t)n * C + c0) * vox + v0;
+        PackVec<T, 4> x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * kThreads, c = i >> 4, vq = i & 15;
+            x[k] = *reinterpret_cast<const PackVec<T, 4>*>(sb + (size_t)c * vox + vq * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * kThreads, c = i >> 4, vq = i & 15;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[c][vq * 4 + e] = (int32_t)x[k].v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * kThreads, v = i >> 4, q = i & 15;
+            *reinterpret_cast<int4*>(db + (size_t)v * C + q * 4) =
+                make_int4(tile[q * 4 + 0][v], tile[q * 4 + 1][v], tile[q * 4 + 2][v], tile[q * 4 + 3][v]);
+        }
+    } else if (channels_first) {
+        const T* sb = src + ((size_t)n * C + c0) * vox + v0;
+        for (int i = threadIdx.x; i < nc * kPackT; i += kThreads) {
+            const int c = i / kPackT, v = i % kPackT;
+            if (v < nv) tile[c][v] = (int32_t)sb[(size_t)c * vox + v];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nv * kPackT; i += kThreads) {
+            const int v = i / kPackT, c = i % kPackT;
+            if (c < nc) db[(size_t)v * C + c] = tile[c][v];
+        }
+    } else {
+        const T* sb = src + ((size_t)n * vox + v0) * C + c0;
+        for (int i = threadIdx.x; i < nv * kPackT; i += kThreads) {
+            const int v = i / kPackT, c = i % kPackT;
+            if (c < nc) db[(size_t)v * C + c] = (int32_t)sb[(size_t)v * C + c];
+        }
+    }
+}
+
 // ---- voxelise ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) k_voxelize(const int32_t* __restrict__ pts, const int32_t* __restrict__ block_of,
                                                        long long npts, int B, int D, int H, int W,
@@ -259,6 +399,51 @@ PCC_API int pcc_scale_to_index(pcc_ctx* ctx, const float* sigma, const float* ta
     PCC_CHECK_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_scale_index, dim3(grid_for(n, 4, ctx->num_cu)), dim3(kThreads), 0, (hipStream_t)stream, sigma,
                        table, L, idx, n);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+PCC_API size_t pcc_symbols_tiles(int32_t N, int64_t vox, int32_t C) {
+    if (N <= 0 || vox <= 0 || C <= 0) return 0;
+    return (size_t)N * (size_t)((vox + kPackT - 1) / kPackT) * (size_t)((C + kPackT - 1) / kPackT);
+}
+
+PCC_API int pcc_symbols_pack(pcc_ctx* ctx, const int32_t* src, int32_t N, int64_t vox, int32_t C, int32_t channels_first,
+                             void* dst, int32_t dst_bytes, int32_t* tile_max, void* stream) {
+    PCC_REQUIRE(ctx && src && dst, "pcc_symbols_pack: NULL argument");
+    PCC_REQUIRE(N > 0 && vox > 0 && vox < (1LL << 31) && C > 0, "pcc_symbols_pack: bad dimension");
+    PCC_REQUIRE(dst_bytes == 1 || dst_bytes == 2 || dst_bytes == 4, "pcc_symbols_pack: dst_bytes must be 1, 2 or 4");
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    const int vt = (int)((vox + kPackT - 1) / kPackT), ct = (C + kPackT - 1) / kPackT;
+    const size_t tiles = (size_t)N * vt * ct;
+    PCC_REQUIRE(tiles < (1ull << 31), "pcc_symbols_pack: too many tiles for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    if (dst_bytes == 1)
+        hipLaunchKernelGGL(k_symbols_pack<uint8_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, src, (uint8_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
+    else if (dst_bytes == 2)
+        hipLaunchKernelGGL(k_symbols_pack<int16_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, src, (int16_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
+    else
+        hipLaunchKernelGGL(k_symbols_pack<int32_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, src, (int32_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+PCC_API int pcc_symbols_unpack(pcc_ctx* ctx, const void* src, int32_t src_bytes, int32_t N, int64_t vox, int32_t C,
+                               int32_t channels_first, int32_t* dst, void* stream) {
+    PCC_REQUIRE(ctx && src && dst, "pcc_symbols_unpack: NULL argument");
+    PCC_REQUIRE(N > 0 && vox > 0 && vox < (1LL << 31) && C > 0, "pcc_symbols_unpack: bad dimension");
+    PCC_REQUIRE(src_bytes == 1 || src_bytes == 2 || src_bytes == 4, "pcc_symbols_unpack: src_bytes must be 1, 2 or 4");
+    PCC_CHECK_HIP(hipSetDevice(ctx->device));
+    const int vt = (int)((vox + kPackT - 1) / kPackT), ct = (C + kPackT - 1) / kPackT;
+    const size_t tiles = (size_t)N * vt * ct;
+    PCC_REQUIRE(tiles < (1ull << 31), "pcc_symbols_unpack: too many tiles for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    if (src_bytes == 1)
+        hipLaunchKernelGGL(k_symbols_unpack<uint8_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const uint8_t*)src, dst, (int)vox, C, vt, ct, channels_first);
+    else if (src_bytes == 2)
+        hipLaunchKernelGGL(k_symbols_unpack<int16_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const int16_t*)src, dst, (int)vox, C, vt, ct, channels_first);
+    else
+        hipLaunchKernelGGL(k_symbols_unpack<int32_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const int32_t*)src, dst, (int)vox, C, vt, ct, channels_first);
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;
 }

@@ -366,6 +366,12 @@ PCC_API int pcc_profile_read(pcc_ctx* ctx, float* ms, int32_t cap, int32_t* n) {
 }
 
 // ---- graph phases (src/model_types.py:283-309 V1, :371-411 V2) ------------------------------------------------------------
+static int check_io(const pcc_symbol_io* io, const char* who) {
+    PCC_REQUIRE(!io || ((io->sym_bytes == 2 || io->sym_bytes == 4) && (io->idx_bytes == 1 || io->idx_bytes == 4)),
+                "%s: io widths must be 2|4 (symbols) and 1|4 (indexes)", who);
+    return PCC_OK;
+}
+
 static int check_codec(const pcc_codec_desc* c) {
     PCC_REQUIRE(c && (c->version == 1 || c->version == 2) && c->filters > 0, "pcc_codec: bad descriptor (version / filters)");
     PCC_REQUIRE(c->w_synthesis && c->synthesis >= 0, "pcc_codec: the synthesis transform is required");
@@ -396,7 +402,7 @@ PCC_API int pcc_codec_encode(pcc_ctx* ctx, const pcc_codec_desc* c, const float*
                              float* y, float* z, int32_t* zsym, float* z_hat, float* sigma, int32_t* idx, int32_t* ysym,
                              float* y_hat, float* x_hat, const float* thr, float* xyz, int32_t* counts, int64_t cap,
                              int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags,
-                             int32_t final_flags, void* symbols_ready, void* stream) {
+                             int32_t final_flags, const pcc_symbol_io* sink, void* symbols_ready, void* stream) {
     int rc = check_codec(c);
     if (rc != PCC_OK) return rc;
     PCC_REQUIRE(c->analysis >= 0 && c->w_analysis, "pcc_codec_encode: the analysis transform is required");
@@ -426,6 +432,25 @@ PCC_API int pcc_codec_encode(pcc_ctx* ctx, const pcc_codec_desc* c, const float*
         rc = pcc_quantize(ctx, y, nullptr, ysym, y_hat, ny, F, c->round_mode, stream);
         if (rc != PCC_OK) return rc;
     }
+    // the symbols leave in the coder's stream order and integer width: packed here, in order, so that the caller's side stream
+    // carries one copy and no kernel
+    if (sink) {
+        rc = check_io(sink, "pcc_codec_encode");
+        if (rc != PCC_OK) return rc;
+        const int64_t vy = (int64_t)(D / 8) * (H / 8) * (W / 8), vz = (int64_t)(D / 16) * (H / 16) * (W / 16);
+        if (sink->ysym) {
+            rc = pcc_symbols_pack(ctx, ysym, N, vy, F, sink->channels_first, sink->ysym, sink->sym_bytes, sink->ysym_tile_max, stream);
+            if (rc != PCC_OK) return rc;
+        }
+        if (c->version == 2 && sink->zsym) {
+            rc = pcc_symbols_pack(ctx, zsym, N, vz, F, sink->channels_first, sink->zsym, sink->sym_bytes, sink->zsym_tile_max, stream);
+            if (rc != PCC_OK) return rc;
+        }
+        if (c->version == 2 && sink->idx) {
+            rc = pcc_symbols_pack(ctx, idx, N, vy, F, sink->channels_first, sink->idx, sink->idx_bytes, nullptr, stream);
+            if (rc != PCC_OK) return rc;
+        }
+    }
     // everything the range coder needs is final here: the caller's copy stream / host coder can start while the synthesis
     // transform (most of the work) is still being enqueued and executed
     if (symbols_ready) PCC_CHECK_HIP(hipEventRecord((hipEvent_t)symbols_ready, (hipStream_t)stream));
@@ -438,35 +463,49 @@ PCC_API int pcc_codec_encode(pcc_ctx* ctx, const pcc_codec_desc* c, const float*
 }
 
 // V2 decoder, first phase (model_types.py:403-406): z symbols -> z_hat -> sigma -> indexes.
-PCC_API int pcc_codec_decode_hyper(pcc_ctx* ctx, const pcc_codec_desc* c, const int32_t* zsym, int32_t N, int32_t D, int32_t H,
+PCC_API int pcc_codec_decode_hyper(pcc_ctx* ctx, const pcc_codec_desc* c, int32_t* zsym, int32_t N, int32_t D, int32_t H,
                                    int32_t W, float* z_hat, float* sigma, int32_t* idx, void* workspace, size_t workspace_bytes,
-                                   int32_t layer_flags, void* stream) {
+                                   int32_t layer_flags, const pcc_symbol_io* io, void* stream) {
     int rc = check_codec(c);
     if (rc != PCC_OK) return rc;
     PCC_REQUIRE(c->version == 2 && ctx && zsym && z_hat && sigma && idx, "pcc_codec_decode_hyper: version-2 codec and non-NULL tensors");
     PCC_REQUIRE(D % 16 == 0 && H % 16 == 0 && W % 16 == 0, "pcc_codec_decode_hyper: block edges must be multiples of 16");
     const int F = c->filters;
     const size_t nz = (size_t)N * (D / 16) * (H / 16) * (W / 16) * F, ny = (size_t)N * (D / 8) * (H / 8) * (W / 8) * F;
+    rc = check_io(io, "pcc_codec_decode_hyper");
+    if (rc != PCC_OK) return rc;
+    if (io && io->zsym) {      // stream-order symbols as the host->device copy delivered them -> NDHWC int32
+        rc = pcc_symbols_unpack(ctx, io->zsym, io->sym_bytes, N, (int64_t)(nz / F / N), F, io->channels_first, zsym, stream);
+        if (rc != PCC_OK) return rc;
+    }
     rc = pcc_dequantize(ctx, zsym, c->medians, z_hat, nz, F, stream);
     if (rc != PCC_OK) return rc;
     rc = pcc_network_forward(ctx, PCC_NET_HYPER_SYNTHESIS, F, c->w_hyper_synthesis, z_hat, N, D / 16, H / 16, W / 16, sigma,
                              workspace, workspace_bytes, layer_flags, 0, stream);
     if (rc != PCC_OK) return rc;
-    return pcc_scale_to_index(ctx, sigma, c->scale_table, c->scale_levels, idx, ny, stream);
+    rc = pcc_scale_to_index(ctx, sigma, c->scale_table, c->scale_levels, idx, ny, stream);
+    if (rc != PCC_OK || !io || !io->idx) return rc;
+    return pcc_symbols_pack(ctx, idx, N, (int64_t)(ny / F / N), F, io->channels_first, io->idx, io->idx_bytes, nullptr, stream);
 }
 
 // Decoder, main phase (model_types.py:305-307 V1, :407-408 V2): y symbols -> y_hat -> x_hat, then (optionally, thr != NULL)
 // the thresholding + order-preserving compaction of model_types.py:232-234 in the same call.
-PCC_API int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, const int32_t* ysym, int32_t N, int32_t D, int32_t H,
+PCC_API int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, int32_t* ysym, int32_t N, int32_t D, int32_t H,
                                   int32_t W, float* y_hat, float* x_hat, const float* thr, float* xyz, int32_t* counts,
                                   int64_t cap, int32_t* scratch, void* workspace, size_t workspace_bytes, int32_t layer_flags,
-                                  void* stream) {
+                                  const pcc_symbol_io* io, void* stream) {
     int rc = check_codec(c);
     if (rc != PCC_OK) return rc;
     PCC_REQUIRE(ctx && ysym && y_hat && x_hat, "pcc_codec_decode_main: NULL argument");
     PCC_REQUIRE(D % 8 == 0 && H % 8 == 0 && W % 8 == 0, "pcc_codec_decode_main: block edges must be multiples of 8");
     const int F = c->filters;
     const size_t ny = (size_t)N * (D / 8) * (H / 8) * (W / 8) * F;
+    rc = check_io(io, "pcc_codec_decode_main");
+    if (rc != PCC_OK) return rc;
+    if (io && io->ysym) {
+        rc = pcc_symbols_unpack(ctx, io->ysym, io->sym_bytes, N, (int64_t)(ny / F / N), F, io->channels_first, ysym, stream);
+        if (rc != PCC_OK) return rc;
+    }
     rc = pcc_dequantize(ctx, ysym, c->version == 1 ? c->medians : nullptr, y_hat, ny, F, stream);
     if (rc != PCC_OK) return rc;
     rc = pcc_network_forward(ctx, c->synthesis, F, c->w_synthesis, y_hat, N, D / 8, H / 8, W / 8, x_hat, workspace,

@@ -179,32 +179,33 @@ class CompressionModel:
             self._copy_stream = torch.cuda.Stream(ctx.device)
         return self._copy_stream
 
-    def _copy_out(self, ctx, pairs, ready=None):
-        """Device->pinned-host copies (after the permutation into stream order) on a side stream; returns the event the host
-        has to wait for.  `ready`: event after which the sources are final (default: now, on the main stream).
-        pairs: (dst, src) or (dst, src, probe): when dst is narrower than src (int16 symbols / uint8 CDF rows: a third of the
-        PCIe bytes, and of the time the copy kernels hold CUs beside the synthesis) the value is narrowed on the GPU; `probe`
-        (a pinned int32 scalar) then receives max|src| so that the host can tell whether int16 was enough."""
+    def _staging(self, ctx, slot, B, y_dhw, z_dhw=None):
+        """Per pipeline slot: the device + pinned staging buffers of one encode (ops.SymbolStaging), cached."""
+        sym_t, row_t = _host_dtypes()
+        F = self.num_filters
+        key = (ctx.device.index, slot, B, tuple(y_dhw), None if z_dhw is None else tuple(z_dhw), sym_t, self.data_format)
+        cache = self.__dict__.setdefault('_stagings', {})
+        if key not in cache:
+            cache[key] = ops.SymbolStaging(ctx.device, B, self._stream_shape(B, y_dhw, F),
+                                           None if z_dhw is None else self._stream_shape(B, z_dhw, F), F, sym_t, row_t,
+                                           self.data_format == 'channels_first')
+        return cache[key]
+
+    def _ship(self, ctx, staging, ready=None):
+        """ONE device->pinned-host copy of a packed staging buffer on the side stream (no kernel runs there: the permutation
+        into stream order, the narrowing and the max|symbol| tiles were written in order on the main stream by the library);
+        returns the event the host has to wait for.  `ready`: event after which the staging buffer is final (default: now,
+        on the main stream)."""
         main = torch.cuda.current_stream(ctx.device)
-        if not hasattr(self, '_copy_stream'):
-            self._copy_stream = torch.cuda.Stream(ctx.device)
+        side = self._side_stream(ctx)
         if ready is None:
             ready = torch.cuda.Event()
             ready.record(main)
-        with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(ready)
-            for item in pairs:
-                dst, src = item[0], item[1]
-                src.record_stream(self._copy_stream)
-                src = self._to_stream_order(src)
-                if dst.dtype != src.dtype:
-                    if len(item) > 2 and item[2] is not None:
-                        item[2].copy_(src.abs().amax().reshape(1), non_blocking=True)
-                    src = src.to(dst.dtype)
-                dst.copy_(src, non_blocking=True)
-                src.record_stream(self._copy_stream)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            staging.copy_out()
             done = torch.cuda.Event()
-            done.record(self._copy_stream)
+            done.record(side)
         return done
 
     # ---- symbol order of the range-coded streams.  tfc 1.3 codes each batch item's tensor flattened in ITS memory order:
@@ -293,20 +294,29 @@ class CompressionModel:
                                  list(nets.values()))
         return self._codec_cache[1][0]
 
-    def _decode_symbols(self, ctx, table, strings, n, index_list, index_mod, sym_h, release):
-        """Range-decodes one stream per block into the int16 pinned buffer `sym_h` (B, ...), moves it to the GPU (half the PCIe
-        bytes of int32) and returns the int32 (B,D,H,W,C) device tensor.  A symbol beyond int16 (OverflowError from the coder:
-        never seen in practice) repeats the decode into int32."""
+    def _range_decode(self, table, strings, n, index_list, index_mod, sym_h):
+        """Range-decodes one stream per block into the narrow pinned buffer `sym_h` (B, ...) in stream order; returns sym_h, or
+        -- when a symbol does not fit it (OverflowError from the coder: never seen in practice) -- an int32 array of the same
+        shape."""
         B = len(strings)
         try:
             ops.range_decode_batch(table, strings, [n] * B, index_list, index_mod, self.coder_threads,
                                    out=[sym_h[b].numpy().reshape(-1) for b in range(B)])
-            dev = sym_h.to(ctx.device, non_blocking=True)
-            release(torch.cuda.current_stream(ctx.device))
+            return sym_h
         except OverflowError:
             wide = ops.range_decode_batch(table, strings, [n] * B, index_list, index_mod, self.coder_threads)
-            dev = torch.from_numpy(np.stack(wide).reshape(sym_h.shape)).to(ctx.device)
-        return self._from_stream_order(dev.to(torch.int32))
+            return torch.from_numpy(np.stack(wide).reshape(sym_h.shape))
+
+    def _symbols_to_device(self, ctx, sym_host, release):
+        """Stream-order host symbols -> the device, as they are (one host->device copy of the narrow integers: half the PCIe
+        bytes of int32).  The library unpacks them into the int32 (B,D,H,W,C) tensor inside the decoder call
+        (pcc_symbol_io); the per-layer path calls ops.symbols_unpack."""
+        dev = sym_host.to(ctx.device, non_blocking=True)
+        release(torch.cuda.current_stream(ctx.device))
+        return dev
+
+    def _unpack(self, ctx, packed, dhw):
+        return ops.symbols_unpack(ctx, packed, (packed.shape[0],) + tuple(dhw) + (self.num_filters,), self.data_format == 'channels_first')
 
     def _gather_points(self, xyz, counts, ctx=None, ready=None):
         """Point lists to the host.  When `ready` (an event recorded after the compaction kernels) is given, the
@@ -349,6 +359,7 @@ class CompressionModel:
         medians / scale table tensors and the pcc_codec_desc, which holds raw device pointers to them."""
         self._dev_cache.clear()
         self._codec_cache = (None,)
+        self.__dict__.pop('_stagings', None)
 
     def get_weights(self):
         out = {}
@@ -712,17 +723,18 @@ class CompressionModelV1(CompressionModel):
         codec = self._codec(ctx)
         t = {}
         ready = None
+        stg = self._staging(ctx, slot, B, [v // 8 for v in x.shape[1:4]])
         if codec is not None:                      # analysis -> quantise -> synthesis (-> fixed threshold) in one ABI call
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(ctx.device))      # creates the handle; re-recorded by the library
-            t = ops.codec_encode(ctx, codec, x.contiguous(), thr, symbols_ready=ready)
+            t = ops.codec_encode(ctx, codec, x.contiguous(), thr, symbols_ready=ready, staging=stg)
             y, ysym, y_hat, x_hat = t['y'], t['symbols'], t['y_hat'], t['x_hat']
         else:
             med = self._dev(ctx, 'medians', eb.medians)
             y = self.analysis_transform.forward_ndhwc(ctx, x.unsqueeze(-1))
             ysym, y_hat = ops.quantize(ctx, y, med, self.round_mode)
-        ysym_h = self._pinned.get(('ysym', slot), self._stream_shape(B, ysym.shape[1:4], self.num_filters), torch.int32)
-        ev = self._copy_out(ctx, [(ysym_h, ysym)], ready)
+            stg.pack(ctx, ysym)
+        ev = self._ship(ctx, stg, ready)
         if codec is None:
             x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
             if thr is not None:
@@ -731,7 +743,9 @@ class CompressionModelV1(CompressionModel):
 
         def finish():
             ev.synchronize()
-            ys = ops.range_encode_batch(eb.table, [ysym_h[b] for b in range(B)], None if rows is None else [rows] * B, mod,
+            # a symbol beyond the narrow host type (never seen in practice) shows in the tile maxima: fetch that tensor as int32
+            ys_src = stg.ysym if stg.sym_dtype == torch.int32 or int(stg.ytm.max()) <= 32767 else self._to_stream_order(ysym).cpu()
+            ys = ops.range_encode_batch(eb.table, [ys_src[b] for b in range(B)], None if rows is None else [rows] * B, mod,
                                         self.coder_threads)
             return [(s,) for s in ys]
 
@@ -743,22 +757,21 @@ class CompressionModelV1(CompressionModel):
         B = len(strings)
         eb = self.entropy_bottleneck
         yshape = self._stream_shape(B, [v // 8 for v in dhw], self.num_filters)
-        ysym_h, ysym_release = self._pinned.ring('dec_ysym', yshape, torch.int32)
+        ysym_h, ysym_release = self._pinned.ring('dec_ysym', yshape, _host_dtypes()[0])
         n = int(np.prod(yshape[1:]))
         rows, mod = self._eb_rows(n, self.num_filters)
-        ops.range_decode_batch(eb.table, [s[0] for s in strings], [n] * B, None if rows is None else [rows] * B, mod,
-                               self.coder_threads, out=[ysym_h[b].numpy() for b in range(B)])
-        return dict(ysym_h=ysym_h, ysym_release=ysym_release)
+        return dict(ysym=self._range_decode(eb.table, [s[0] for s in strings], n, None if rows is None else [rows] * B, mod, ysym_h),
+                    ysym_release=ysym_release)
 
     def _decode_phase_b(self, ctx, st, dhw, debug, thr=None):
         eb = self.entropy_bottleneck
-        ysym = self._from_stream_order(st['ysym_h'].to(ctx.device, non_blocking=True))
-        st['ysym_release'](torch.cuda.current_stream(ctx.device))
+        packed = self._symbols_to_device(ctx, st['ysym'], st['ysym_release'])
         codec = self._codec(ctx)
-        if codec is not None:                      # dequantise -> synthesis (-> threshold + compaction) in one ABI call
-            t = ops.codec_decode_main(ctx, codec, ysym, dhw, thr)
+        if codec is not None:                      # unpack -> dequantise -> synthesis (-> threshold + compaction) in one ABI call
+            t = ops.codec_decode_main(ctx, codec, None, dhw, thr, packed=packed, channels_first=self.data_format == 'channels_first')
             y_hat, x_hat = t['y_hat'], t['x_hat']
         else:
+            ysym = self._unpack(ctx, packed, [v // 8 for v in dhw])
             y_hat = ops.dequantize(ctx, ysym, self._dev(ctx, 'medians', eb.medians))
             x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
             t = {}
@@ -837,10 +850,11 @@ class CompressionModelV2(CompressionModel):
         codec = self._codec(ctx)
         t = {}
         ready = None
+        stg = self._staging(ctx, slot, B, [v // 8 for v in x.shape[1:4]], [v // 16 for v in x.shape[1:4]])
         if codec is not None:                      # the whole GPU part of compress() (model_types.py:379-388) in one ABI call
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(ctx.device))      # creates the handle; re-recorded by the library
-            t = ops.codec_encode(ctx, codec, x.contiguous(), thr, symbols_ready=ready)
+            t = ops.codec_encode(ctx, codec, x.contiguous(), thr, symbols_ready=ready, staging=stg)
             y, z, zsym, z_hat, sigma, idx, ysym, y_hat, x_hat = (t[k] for k in ('y', 'z', 'z_symbols', 'z_hat', 'sigma_hat',
                                                                                 'indexes', 'symbols', 'y_hat', 'x_hat'))
         else:
@@ -852,16 +866,12 @@ class CompressionModelV2(CompressionModel):
             sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
             idx = ops.scale_to_index(ctx, sigma, tab)
             ysym, y_hat = ops.quantize(ctx, y, None, self.round_mode)
-        # what crosses PCIe: symbols as int16, the 64 scale rows as uint8 (8.5 -> 3.3 MB per 32-block chunk); `probe` tells the
-        # host afterwards whether a symbol exceeded int16 (then that tensor is fetched again as int32: never seen in practice)
-        sym_t, row_t = _host_dtypes()
-        zsym_h = self._pinned.get(('zsym', slot), self._stream_shape(B, zsym.shape[1:4], F), sym_t)
-        ysym_h = self._pinned.get(('ysym', slot), self._stream_shape(B, ysym.shape[1:4], F), sym_t)
-        idx_h = self._pinned.get(('idx', slot), self._stream_shape(B, idx.shape[1:4], F), row_t)
-        probe = self._pinned.get(('probe', slot), (2,), torch.int32)
-        # symbols leave on a side stream (permutation into stream order + copy) so that they overlap the synthesis transform:
-        # `ready` is recorded by the library between the last quantiser and the first synthesis layer
-        ev = self._copy_out(ctx, [(zsym_h, zsym, probe[0:1]), (ysym_h, ysym, probe[1:2]), (idx_h, idx)], ready)
+            stg.pack(ctx, ysym, zsym, idx)
+        # what crosses PCIe: ONE buffer per chunk -- symbols as int16, the 64 scale rows as uint8 (8.5 -> 3.3 MB per 32-block
+        # chunk), packed in stream order by the library before `ready`, plus the per-tile max|symbol| that tells the host
+        # afterwards whether a symbol exceeded int16 (then that tensor is fetched again as int32: never seen in practice).
+        # The copy runs on a side stream so that it overlaps the synthesis transform.
+        ev = self._ship(ctx, stg, ready)
         if codec is None:
             x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
             if thr is not None:
@@ -870,12 +880,12 @@ class CompressionModelV2(CompressionModel):
 
         def finish():
             ev.synchronize()  # symbols are on the host
-            fits = sym_t == torch.int32
-            zs_src = zsym_h if fits or int(probe[0]) <= 32767 else self._to_stream_order(zsym).cpu()
-            ys_src = ysym_h if fits or int(probe[1]) <= 32767 else self._to_stream_order(ysym).cpu()
+            fits = stg.sym_dtype == torch.int32
+            zs_src = stg.zsym if fits or int(stg.ztm.max()) <= 32767 else self._to_stream_order(zsym).cpu()
+            ys_src = stg.ysym if fits or int(stg.ytm.max()) <= 32767 else self._to_stream_order(ysym).cpu()
             zs = ops.range_encode_batch(eb.table, [zs_src[b] for b in range(B)], None if rows is None else [rows] * B, mod,
                                         self.coder_threads)
-            ys = ops.range_encode_batch(gc.table, [ys_src[b] for b in range(B)], [idx_h[b] for b in range(B)], 0,
+            ys = ops.range_encode_batch(gc.table, [ys_src[b] for b in range(B)], [stg.idx[b] for b in range(B)], 0,
                                         self.coder_threads)
             return list(zip(ys, zs))  # strings = (y_string, z_string), model_types.py:389
 
@@ -896,18 +906,24 @@ class CompressionModelV2(CompressionModel):
         zsym_h, zsym_release = self._pinned.ring('dec_zsym', zshape, _host_dtypes()[0])
         nz = int(np.prod(zshape[1:]))
         rows, mod = self._eb_rows(nz, F)
-        zsym = self._decode_symbols(ctx, eb.table, [s[1] for s in strings], nz, None if rows is None else [rows] * B, mod, zsym_h, zsym_release)
+        zpacked = self._symbols_to_device(ctx, self._range_decode(eb.table, [s[1] for s in strings], nz,
+                                                                  None if rows is None else [rows] * B, mod, zsym_h), zsym_release)
+        # the 64 scale rows leave in stream order, one byte each
+        row_t = _host_dtypes()[1]
+        cf = self.data_format == 'channels_first'
+        idx_s = torch.empty(self._stream_shape(B, [v // 8 for v in dhw], F), dtype=row_t, device=ctx.device)
         codec = self._codec(ctx)
-        if codec is not None:                      # dequantise z -> hyper-synthesis -> indexes in one ABI call
-            t = ops.codec_decode_hyper(ctx, codec, zsym, dhw)
+        if codec is not None:                      # unpack z -> dequantise -> hyper-synthesis -> indexes -> pack, one ABI call
+            t = ops.codec_decode_hyper(ctx, codec, None, dhw, packed=zpacked, channels_first=cf, idx_packed=idx_s)
             z_hat, sigma, idx = t['z_hat'], t['sigma_hat'], t['indexes']
         else:
+            zsym = self._unpack(ctx, zpacked, [v // 16 for v in dhw])
             z_hat = ops.dequantize(ctx, zsym, self._dev(ctx, 'medians', eb.medians))
             sigma = self.hyper_synthesis_transform.forward_ndhwc(ctx, z_hat)
             idx = ops.scale_to_index(ctx, sigma, self._dev(ctx, 'scale_table', gc.scale_table_f32))
-        idx_s = self._to_stream_order(idx).to(_host_dtypes()[1])      # 64 scale rows: one byte each over PCIe
+            ops.symbols_pack(ctx, idx, cf, idx_s.data_ptr(), idx_s.element_size())
         # (the host reads idx_h synchronously in phase b, long before the ring comes round: no release event needed)
-        idx_h, _ = self._pinned.ring('dec_idx', idx_s.shape, _host_dtypes()[1])
+        idx_h, _ = self._pinned.ring('dec_idx', idx_s.shape, row_t)
         idx_h.copy_(idx_s, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(ctx.device))
@@ -921,12 +937,14 @@ class CompressionModelV2(CompressionModel):
         st['ev'].synchronize()
         ysym_h, ysym_release = self._pinned.ring('dec_ysym', idx_h.shape, _host_dtypes()[0])
         n = int(np.prod(idx_h.shape[1:]))
-        ysym = self._decode_symbols(ctx, gc.table, [s[0] for s in strings], n, [idx_h[b] for b in range(B)], 0, ysym_h, ysym_release)
+        packed = self._symbols_to_device(ctx, self._range_decode(gc.table, [s[0] for s in strings], n, [idx_h[b] for b in range(B)], 0,
+                                                                 ysym_h), ysym_release)
         codec = self._codec(ctx)
-        if codec is not None:                      # dequantise -> synthesis (-> threshold + compaction) in one ABI call
-            t = ops.codec_decode_main(ctx, codec, ysym, dhw, thr)
-            y_hat, x_hat = t['y_hat'], t['x_hat']
+        if codec is not None:                      # unpack -> dequantise -> synthesis (-> threshold + compaction) in one ABI call
+            t = ops.codec_decode_main(ctx, codec, None, dhw, thr, packed=packed, channels_first=self.data_format == 'channels_first')
+            ysym, y_hat, x_hat = t['symbols'], t['y_hat'], t['x_hat']
         else:
+            ysym = self._unpack(ctx, packed, [v // 8 for v in dhw])
             y_hat = ops.dequantize(ctx, ysym, None)
             x_hat = self.synthesis_transform.forward_ndhwc(ctx, y_hat)[..., 0].contiguous()
             t = {}

@@ -244,11 +244,85 @@ def codec_desc(ctx, version, filters, nets, medians=None, scale_table=None, roun
     return d, keep
 
 
-def codec_encode(ctx, desc, x, thr=None, cap=None, symbols_ready=None):
+_ITEM = {torch.uint8: 1, torch.int16: 2, torch.int32: 4}
+
+
+class SymbolStaging:
+    """What leaves the device for the host coder after one encode of B blocks, as ONE buffer: z symbols, y symbols, CDF-row
+    indexes (stream order, narrow integers) and the per-tile max|symbol| of both symbol tensors.  `dev` (device uint8) is
+    filled by the library (pcc_symbol_io / pcc_symbols_pack), `host` (pinned uint8) receives it in one copy; the
+    attributes zsym / ysym / idx / ztm / ytm are views of `host`.  z pieces are absent for a version-1 codec."""
+
+    def __init__(self, device, B, stream_shape_y, stream_shape_z, F, sym_dtype, idx_dtype, channels_first):
+        self.sym_dtype, self.idx_dtype, self.channels_first = sym_dtype, idx_dtype, bool(channels_first)
+        vy = int(np.prod(stream_shape_y[1:])) // F
+        vz = int(np.prod(stream_shape_z[1:])) // F if stream_shape_z is not None else 0
+        self.vy, self.vz, self.B, self.F = vy, vz, B, F
+        pieces = [('ysym', stream_shape_y, sym_dtype)]
+        if stream_shape_z is not None:
+            pieces += [('zsym', stream_shape_z, sym_dtype), ('idx', stream_shape_y, idx_dtype)]
+        pieces.append(('ytm', (L.lib().pcc_symbols_tiles(B, vy, F),), torch.int32))
+        if stream_shape_z is not None:
+            pieces.append(('ztm', (L.lib().pcc_symbols_tiles(B, vz, F),), torch.int32))
+        off, self.layout = 0, {}
+        for name, shape, dt in pieces:
+            nbytes = int(np.prod(shape)) * _ITEM[dt]
+            self.layout[name] = (off, nbytes, tuple(shape), dt)
+            off += (nbytes + 15) // 16 * 16
+        self.nbytes = off
+        self.dev = torch.empty((off,), dtype=torch.uint8, device=device)
+        self.host = torch.empty((off,), dtype=torch.uint8, pin_memory=True)
+        for name, (o, nb, shape, dt) in self.layout.items():
+            setattr(self, name, self.host[o:o + nb].view(dt).reshape(shape))
+
+    def dev_ptr(self, name):
+        return self.dev.data_ptr() + self.layout[name][0] if name in self.layout else None
+
+    def sink(self):
+        k = L.SymbolSink()
+        k.zsym, k.ysym, k.idx = self.dev_ptr('zsym'), self.dev_ptr('ysym'), self.dev_ptr('idx')
+        k.zsym_tile_max, k.ysym_tile_max = self.dev_ptr('ztm'), self.dev_ptr('ytm')
+        k.sym_bytes, k.idx_bytes, k.channels_first = _ITEM[self.sym_dtype], _ITEM[self.idx_dtype], int(self.channels_first)
+        return k
+
+    def pack(self, ctx, ysym, zsym=None, idx=None):
+        """the same packing from Python (the per-layer path, which has no pcc_codec_encode call to do it)"""
+        symbols_pack(ctx, ysym, self.channels_first, self.dev_ptr('ysym'), _ITEM[self.sym_dtype], self.dev_ptr('ytm'))
+        if zsym is not None:
+            symbols_pack(ctx, zsym, self.channels_first, self.dev_ptr('zsym'), _ITEM[self.sym_dtype], self.dev_ptr('ztm'))
+            symbols_pack(ctx, idx, self.channels_first, self.dev_ptr('idx'), _ITEM[self.idx_dtype], None)
+
+    def copy_out(self):
+        """device -> pinned host on the current stream (one copy)"""
+        self.host.copy_(self.dev, non_blocking=True)
+
+
+def symbols_pack(ctx, src, channels_first, dst_ptr, dst_bytes, tile_max_ptr=None):
+    """(N, ..., C) int32 device tensor -> stream order, dst_bytes-wide integers at the device address dst_ptr."""
+    assert src.dtype == torch.int32 and src.is_contiguous() and src.device == ctx.device
+    N, Cc = src.shape[0], src.shape[-1]
+    L.check(L.lib().pcc_symbols_pack(ctx.handle, _ptr(src), N, src[0].numel() // Cc, Cc, int(bool(channels_first)),
+                                     C.c_void_p(dst_ptr), dst_bytes, None if tile_max_ptr is None else C.c_void_p(tile_max_ptr),
+                                     ctx.stream), 'pcc_symbols_pack')
+
+
+def symbols_unpack(ctx, src, ndhwc_shape, channels_first):
+    """stream-order device tensor (uint8 / int16 / int32) of N blocks -> (N,D,H,W,C) int32 device tensor."""
+    assert src.is_contiguous() and src.device == ctx.device and src.dtype in _ITEM
+    out = torch.empty(tuple(ndhwc_shape), dtype=torch.int32, device=ctx.device)
+    N, Cc = out.shape[0], out.shape[-1]
+    assert src.numel() == out.numel()
+    L.check(L.lib().pcc_symbols_unpack(ctx.handle, _ptr(src), _ITEM[src.dtype], N, out[0].numel() // Cc, Cc,
+                                       int(bool(channels_first)), _ptr(out), ctx.stream), 'pcc_symbols_unpack')
+    return out
+
+
+def codec_encode(ctx, desc, x, thr=None, cap=None, symbols_ready=None, staging=None):
     """The GPU part of compress() (src/model_types.py:289-293 / :379-388) for a batch of blocks in ONE ABI call.
     x: (N,D,H,W) float32.  Returns dict of device tensors (NDHWC); with `thr` (N,) float32 also the encoder-side point
     lists xyz / counts of the clipped x_hat (fixed-threshold policy).  symbols_ready: a torch.cuda.Event that has been
-    recorded once (so that its handle exists); the library re-records it when the symbols are final."""
+    recorded once (so that its handle exists); the library re-records it when the symbols are final.  staging: a
+    SymbolStaging whose device buffer the library fills (stream order, narrow integers) before that event."""
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.device == ctx.device
     N, D, H, W = x.shape
     F, dev = desc.filters, ctx.device
@@ -270,32 +344,66 @@ def codec_encode(ctx, desc, x, thr=None, cap=None, symbols_ready=None):
                                      _ptr(t.get('z_symbols')), _ptr(t.get('z_hat')), _ptr(t.get('sigma_hat')),
                                      _ptr(t.get('indexes')), _ptr(t['symbols']), _ptr(t['y_hat']), _ptr(t['x_hat']), _ptr(thr),
                                      _ptr(xyz), _ptr(counts), cap, _ptr(scratch), _ptr(ws), ws.numel(),
-                                     getattr(ctx, 'conv_flags', 0), 0,
+                                     getattr(ctx, 'conv_flags', 0), 0, None if staging is None else C.byref(staging.sink()),
                                      None if symbols_ready is None else C.c_void_p(symbols_ready.cuda_event), ctx.stream),
             'pcc_codec_encode')
     return t
 
 
-def codec_decode_hyper(ctx, desc, zsym, dhw):
-    """z symbols (N,D/16,H/16,W/16,F) int32 -> z_hat, sigma_hat, indexes (src/model_types.py:403-406), one ABI call."""
-    N, (D, H, W), F, dev = zsym.shape[0], dhw, desc.filters, ctx.device
-    assert zsym.dtype == torch.int32 and zsym.is_contiguous() and tuple(zsym.shape) == (N, D // 16, H // 16, W // 16, F)
-    ys = (N, D // 8, H // 8, W // 8, F)
-    t = dict(z_hat=torch.empty(zsym.shape, dtype=torch.float32, device=dev), sigma_hat=torch.empty(ys, dtype=torch.float32, device=dev),
-             indexes=torch.empty(ys, dtype=torch.int32, device=dev))
+def _packed_io(packed, channels_first, idx_out=None):
+    """pcc_symbol_io for the decoder calls: `packed` = stream-order symbols on the device (int16 / int32) as the host->device
+    copy delivered them, idx_out = device tensor (uint8 / int32) that receives the packed CDF-row indexes."""
+    k = L.SymbolSink()
+    k.sym_bytes = _ITEM[packed.dtype]
+    k.idx_bytes = 1 if idx_out is None else _ITEM[idx_out.dtype]
+    k.channels_first = int(bool(channels_first))
+    k.idx = None if idx_out is None else idx_out.data_ptr()
+    return k
+
+
+def codec_decode_hyper(ctx, desc, zsym, dhw, packed=None, channels_first=True, idx_packed=None):
+    """z symbols (N,D/16,H/16,W/16,F) int32 -> z_hat, sigma_hat, indexes (src/model_types.py:403-406), one ABI call.
+    packed: instead of zsym, the stream-order symbols (N, ...) int16 / int32 on the device -- the library unpacks them (the
+    int32 tensor comes back as 'z_symbols'); idx_packed: device tensor (uint8 / int32, stream order) that receives the indexes."""
+    (D, H, W), F, dev = dhw, desc.filters, ctx.device
+    N = (zsym if packed is None else packed).shape[0]
+    zs, ys = (N, D // 16, H // 16, W // 16, F), (N, D // 8, H // 8, W // 8, F)
+    io = None
+    if packed is not None or idx_packed is not None:
+        src = packed if packed is not None else torch.empty((0,), dtype=torch.int16)
+        io = _packed_io(src, channels_first, idx_packed)
+        if packed is not None:
+            assert packed.is_contiguous() and packed.device == dev and packed.numel() == int(np.prod(zs))
+            io.zsym = packed.data_ptr()
+            zsym = torch.empty(zs, dtype=torch.int32, device=dev)
+        assert idx_packed is None or (idx_packed.is_contiguous() and idx_packed.numel() == int(np.prod(ys)))
+    assert zsym.dtype == torch.int32 and zsym.is_contiguous() and tuple(zsym.shape) == zs
+    t = dict(z_hat=torch.empty(zs, dtype=torch.float32, device=dev), sigma_hat=torch.empty(ys, dtype=torch.float32, device=dev),
+             indexes=torch.empty(ys, dtype=torch.int32, device=dev), z_symbols=zsym)
     ws = ctx.workspace(L.lib().pcc_codec_workspace_bytes(C.byref(desc), N, D, H, W))
     L.check(L.lib().pcc_codec_decode_hyper(ctx.handle, C.byref(desc), _ptr(zsym), N, D, H, W, _ptr(t['z_hat']), _ptr(t['sigma_hat']),
-                                           _ptr(t['indexes']), _ptr(ws), ws.numel(), getattr(ctx, 'conv_flags', 0), ctx.stream),
+                                           _ptr(t['indexes']), _ptr(ws), ws.numel(), getattr(ctx, 'conv_flags', 0),
+                                           None if io is None else C.byref(io), ctx.stream),
             'pcc_codec_decode_hyper')
     return t
 
 
-def codec_decode_main(ctx, desc, ysym, dhw, thr=None, cap=None):
+def codec_decode_main(ctx, desc, ysym, dhw, thr=None, cap=None, packed=None, channels_first=True):
     """y symbols -> y_hat -> x_hat (+ thresholding and compaction when `thr` (N,) float32 is given), one ABI call
-    (src/model_types.py:305-307 / :407-408, :232-234)."""
-    N, (D, H, W), F, dev = ysym.shape[0], dhw, desc.filters, ctx.device
-    assert ysym.dtype == torch.int32 and ysym.is_contiguous() and tuple(ysym.shape) == (N, D // 8, H // 8, W // 8, F)
-    t = dict(y_hat=torch.empty(ysym.shape, dtype=torch.float32, device=dev), x_hat=torch.empty((N, D, H, W), dtype=torch.float32, device=dev))
+    (src/model_types.py:305-307 / :407-408, :232-234).  packed: instead of ysym, the stream-order symbols on the device (see
+    codec_decode_hyper); the int32 tensor comes back as 'symbols'."""
+    (D, H, W), F, dev = dhw, desc.filters, ctx.device
+    N = (ysym if packed is None else packed).shape[0]
+    ys = (N, D // 8, H // 8, W // 8, F)
+    io = None
+    if packed is not None:
+        assert packed.is_contiguous() and packed.device == dev and packed.numel() == int(np.prod(ys))
+        io = _packed_io(packed, channels_first)
+        io.ysym = packed.data_ptr()
+        ysym = torch.empty(ys, dtype=torch.int32, device=dev)
+    assert ysym.dtype == torch.int32 and ysym.is_contiguous() and tuple(ysym.shape) == ys
+    t = dict(y_hat=torch.empty(ys, dtype=torch.float32, device=dev), x_hat=torch.empty((N, D, H, W), dtype=torch.float32, device=dev),
+             symbols=ysym)
     xyz = counts = scratch = None
     cap = D * H * W if cap is None else int(cap)
     if thr is not None:
@@ -307,7 +415,8 @@ def codec_decode_main(ctx, desc, ysym, dhw, thr=None, cap=None):
     ws = ctx.workspace(L.lib().pcc_codec_workspace_bytes(C.byref(desc), N, D, H, W))
     L.check(L.lib().pcc_codec_decode_main(ctx.handle, C.byref(desc), _ptr(ysym), N, D, H, W, _ptr(t['y_hat']), _ptr(t['x_hat']),
                                           _ptr(thr), _ptr(xyz), _ptr(counts), cap, _ptr(scratch), _ptr(ws), ws.numel(),
-                                          getattr(ctx, 'conv_flags', 0), ctx.stream), 'pcc_codec_decode_main')
+                                          getattr(ctx, 'conv_flags', 0), None if io is None else C.byref(io), ctx.stream),
+            'pcc_codec_decode_main')
     return t
 
 

@@ -372,3 +372,29 @@ def test_config2_cloud_1024_level4_sharded_equals_single(ctx):
     cloud = np.vstack(cloud) if isinstance(cloud, (list, tuple)) else cloud
     assert len(cloud) == sum(len(b) for b in dec_blocks) and cloud.min() >= 0 and cloud.max() < R
     print(f'cfg2 stand-in: {len(pts)} points, {len(blocks)} blocks, {len(raw)} container bytes, {len(cloud)} decoded points')
+
+
+@pytest.mark.parametrize('shape,dtype,cf', [((3, 8, 8, 8, 64), torch.int16, True), ((2, 4, 4, 4, 64), torch.int16, True),
+                                            ((2, 5, 3, 7, 24), torch.uint8, True), ((2, 8, 8, 8, 32), torch.int32, True),
+                                            ((2, 5, 3, 7, 24), torch.int16, False), ((1, 16, 16, 16, 96), torch.int16, True)])
+def test_symbols_pack_unpack_is_the_stream_order_permutation(ctx, shape, dtype, cf):
+    """pcc_symbols_pack / _unpack == permute(0,4,1,2,3).contiguous().to(narrow) and back (model_types.py:180,254,377: the coder
+    sees each block's tensor in channels_first memory order); the tile maxima report max|value| exactly."""
+    from pcc_geo_cnn_v2_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    hi = 200 if dtype == torch.uint8 else 30000
+    src = torch.randint(0 if dtype == torch.uint8 else -hi, hi, shape, generator=g, dtype=torch.int32).to(ctx.device)
+    if dtype != torch.uint8:
+        src[0, 1, 2, 3, 5] = 70000 if dtype == torch.int32 else 32767
+    B, C = shape[0], shape[-1]
+    vox = int(np.prod(shape[1:4]))
+    ntiles = L.lib().pcc_symbols_tiles(B, vox, C)
+    assert ntiles == B * ((vox + 63) // 64) * ((C + 63) // 64)
+    out = torch.zeros((B, C) + shape[1:4] if cf else shape, dtype=dtype, device=ctx.device)
+    tmax = torch.full((ntiles,), -1, dtype=torch.int32, device=ctx.device)
+    ops.symbols_pack(ctx, src, cf, out.data_ptr(), out.element_size(), tmax.data_ptr())
+    want = (src.permute(0, 4, 1, 2, 3).contiguous() if cf else src).to(dtype)
+    assert torch.equal(out, want)
+    assert int(tmax.max()) == int(src.abs().max()) and int(tmax.min()) >= 0
+    back = ops.symbols_unpack(ctx, out, shape, cf)
+    assert torch.equal(back, src)
