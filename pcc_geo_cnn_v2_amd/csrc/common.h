@@ -54,6 +54,16 @@ int pcc_conv3d_generic(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
                        const float* bias, const float* residual, float* out, hipStream_t st);
 int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed,
                     const float* bias, const float* residual, float* out, hipStream_t st);
+// The fixed-threshold extraction folded into the last layer (16 -> 1 transposed conv, conv_cout1_mfma_kernel): the kernel also
+// writes bit (z,y,x) of block n = (clip ? clamp01(x_hat) : x_hat) > thr[n] into `mask` (one bit per voxel, row-major, 32-bit
+// words little-endian).  *fused tells the caller whether the layer took that path (else: pcc_threshold_compact on x_hat).
+struct pcc_thr_fuse { const float* thr; int clip; uint32_t* mask; };
+int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
+                        const float* residual, float* out, const pcc_thr_fuse* fuse, bool* fused, hipStream_t st);
+// points from the bit mask (elementwise.hip): scratch = [B * D plane counts][B * D*H*W / 32 mask words]
+uint32_t* pcc_threshold_mask_of(int32_t* scratch, int32_t B, int32_t D);
+int pcc_threshold_from_mask(pcc_ctx* ctx, int32_t B, int32_t D, int32_t H, int32_t W, float* xyz, int32_t* counts, int64_t cap,
+                            int32_t* scratch, hipStream_t st);
 // Winograd F(2x2,3x3) (x,y) + direct z path for 16->16 and 32->32 k3 stride-1 layers (conv_wino.hip)
 bool pcc_wino_eligible(const pcc_conv_desc* d);
 int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed,

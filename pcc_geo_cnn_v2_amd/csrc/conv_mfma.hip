@@ -74,6 +74,10 @@ struct ConvArgs {
     int OD, OH, OW;     // output dims
     int ntz, nty, ntx;  // tiles per dim (base grid)
     int flags, ocs, oco;
+    // 16 -> 1 last layer with the occupancy decision folded into its epilogue (pcc_thr_fuse): bit (z,y,x) of `mask` = x_hat > thr[n]
+    const float* thr = nullptr;
+    unsigned short* mask = nullptr;
+    int thr_clip = 0;
 };
 
 __device__ __forceinline__ void store_out(const ConvArgs& a, f32x4 v, size_t vox, int c0, int COUT) {
@@ -1248,7 +1252,11 @@ struct Cout1M {
 
 // IN16 (fp16 mode, PCC_CONV_IN16): the input is fp16 NDHWC; a lane's 4 channels are one 8-byte load and feed ONE
 // v_mfma_f32_16x16x16_f16 per tap tile instead of four fp32 MFMAs.
-template <bool IN16, int T>
+// THR (pcc_thr_fuse, fixed-threshold extraction): the epilogue also decides occupancy -- (clipped) x_hat > thr[n], the float32
+// compare of model_types.py:202,209 / :232-234 -- and stores it as one bit per voxel in (z,y,x) order: a wave's ballot is T-bit
+// pieces of 64 / T output rows, each written once by its row's first lane.  The compaction pass then reads 32 KB per 64^3 block
+// instead of x_hat twice.
+template <bool IN16, int T, bool THR>
 __global__ void __launch_bounds__((Cout1M<T>::NT)) conv_cout1_mfma_kernel(ConvArgs a) {
     using C = Cout1M<T>;
     extern __shared__ __attribute__((aligned(16))) float P[];   // [32][RS]
@@ -1303,12 +1311,29 @@ __global__ void __launch_bounds__((Cout1M<T>::NT)) conv_cout1_mfma_kernel(ConvAr
     float* ob = a.out + ((size_t)n * a.OD * out_plane + (size_t)(y0 + oy) * a.OW + x0 + ox) * a.ocs + a.oco;
     const float* rb = (a.flags & PCC_CONV_ADD) ? a.res + (size_t)n * a.OD * out_plane + (size_t)(y0 + oy) * a.OW + x0 + ox : nullptr;
 
+    float thr_n = 0.f;
+    unsigned short* mrow = nullptr;        // this lane's row of the bit mask (meaningful on the first lane of each T-lane group)
+    if constexpr (THR) {
+        thr_n = a.thr[n];
+        mrow = a.mask + ((size_t)n * a.OD * out_plane + (size_t)(y0 + oy) * a.OW + x0) / 16;
+    }
+
     auto finish = [&](float s, int z) {
         s += bias;
         if (a.flags & PCC_CONV_RELU) s = fmaxf(s, 0.f);
         if (rb) s += rb[(size_t)z * out_plane];
         if (a.flags & PCC_CONV_CLIP01) s = fminf(fmaxf(s, 0.f), 1.f);
         if (col_ok) ob[(size_t)z * out_plane * a.ocs] = s;
+        if constexpr (THR) {
+            const float v = a.thr_clip ? fminf(fmaxf(s, 0.f), 1.f) : s;
+            const unsigned long long hits = __ballot(col_ok && v > thr_n);
+            if ((lane & (T - 1)) == 0 && (y0 + oy) < a.OH) {
+                const unsigned piece = (unsigned)(hits >> (lane & 63 & ~(T - 1)));
+                unsigned short* mp = mrow + (size_t)z * out_plane / 16;
+                if constexpr (T == 32) *reinterpret_cast<unsigned*>(mp) = piece;
+                else *mp = (unsigned short)piece;
+            }
+        }
     };
 
     f32x4 nxt[C::PER_WAVE];
@@ -1720,6 +1745,12 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
 
 int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
                     const float* residual, float* out, hipStream_t st) {
+    return pcc_conv3d_mfma_thr(ctx, d, in, w_packed, bias, residual, out, nullptr, nullptr, st);
+}
+
+int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
+                        const float* residual, float* out, const pcc_thr_fuse* fuse, bool* fused, hipStream_t st) {
+    if (fused) *fused = false;
     const Plan p = make_plan(d);
     PCC_REQUIRE(p.kind != K_NONE, "pcc_conv3d_mfma: shape not covered");
     ConvArgs a;
@@ -1779,6 +1810,12 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
         // 32 x 32 columns (one 16-wave workgroup per CU) when H, W allow it and the grid, z-split into slabs of >= 16 planes, still
         // gives every CU a workgroup; else 16 x 16 columns, whole z range.  PCC_COUT1_T16=1 forces the latter (A/B runs).
         static const bool t16 = getenv("PCC_COUT1_T16") != nullptr;
+        typedef void (*kern_t)(ConvArgs);
+        const bool in16 = (d->flags & PCC_CONV_IN16) != 0;
+        // the occupancy bits ride along when the caller asked for them and whole T-voxel rows map to whole mask pieces
+        const bool thr = fuse != nullptr && a.ocs == 1 && a.oco == 0 && a.W % 16 == 0 && ((size_t)a.H * a.W) % 32 == 0;
+        if (thr) { a.thr = fuse->thr; a.mask = (unsigned short*)fuse->mask; a.thr_clip = fuse->clip; }
+        if (fused) *fused = thr;
         if (!t16 && a.H % 32 == 0 && a.W % 32 == 0) {
             const int base = a.N * (a.H / 32) * (a.W / 32);
             int zsp = 1;
@@ -1786,16 +1823,18 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
             if (base * zsp >= ctx->num_cu) {
                 using C = Cout1M<32>;
                 a.ntz = zsp; a.nty = a.H / 32; a.ntx = a.W / 32;
-                typedef void (*kern_t)(ConvArgs);
-                const kern_t kern = (d->flags & PCC_CONV_IN16) ? (kern_t)conv_cout1_mfma_kernel<true, 32> : (kern_t)conv_cout1_mfma_kernel<false, 32>;
+                static const kern_t k32[4] = {conv_cout1_mfma_kernel<false, 32, false>, conv_cout1_mfma_kernel<true, 32, false>,
+                                              conv_cout1_mfma_kernel<false, 32, true>, conv_cout1_mfma_kernel<true, 32, true>};
+                const kern_t kern = k32[(in16 ? 1 : 0) + (thr ? 2 : 0)];
                 { const int rc = pcc_enable_big_lds((const void*)kern, C::LDS_BYTES); if (rc != PCC_OK) return rc; }
                 return launch(kern, C::NT, C::LDS_BYTES, base * zsp, a, st);
             }
         }
         using C = Cout1M<16>;
         a.ntz = 1; a.nty = cdiv(a.H, C::TYX); a.ntx = cdiv(a.W, C::TYX);
-        if (d->flags & PCC_CONV_IN16) return launch(conv_cout1_mfma_kernel<true, 16>, C::NT, C::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
-        return launch(conv_cout1_mfma_kernel<false, 16>, C::NT, C::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
+        static const kern_t k16[4] = {conv_cout1_mfma_kernel<false, 16, false>, conv_cout1_mfma_kernel<true, 16, false>,
+                                      conv_cout1_mfma_kernel<false, 16, true>, conv_cout1_mfma_kernel<true, 16, true>};
+        return launch(k16[(in16 ? 1 : 0) + (thr ? 2 : 0)], C::NT, C::LDS_BYTES, a.N * a.nty * a.ntx, a, st);
     } else if (p.kind == K_COUT1) {
 #define PCC_COUT1(CI, K, S, TZ, TY, TXT)                                                                \
     if (ci == CI && k == K && s == S) {                                                                 \

@@ -321,6 +321,52 @@ __global__ void __launch_bounds__(kThreads) k_thr_write(const float* __restrict_
     if (c == chunks - 1 && threadIdx.x == 0) counts[b] = offset;
 }
 
+// ---- points from the occupancy bit mask the last layer wrote (pcc_thr_fuse) --------------------------------------------------
+// One workgroup per (z plane, block): pass 1 counts the plane's set bits, pass 2 writes its points behind those of the planes
+// before it (np.argwhere order: z, y, x ascending).  Together they read D*H*W / 8 bytes per block.
+__global__ void __launch_bounds__(kThreads) k_mask_count(const uint32_t* __restrict__ mask, int wpp, int32_t* __restrict__ plane_cnt) {
+    __shared__ int lds4[4];
+    const uint32_t* mp = mask + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * wpp;
+    int cnt = 0;
+    for (int w = threadIdx.x; w < wpp; w += kThreads) cnt += __popc(mp[w]);
+    int total;
+    block_excl_scan(cnt, &total, lds4);
+    if (threadIdx.x == 0) plane_cnt[blockIdx.y * gridDim.x + blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kThreads) k_mask_write(const uint32_t* __restrict__ mask, int wpp, int W,
+                                                         const int32_t* __restrict__ plane_cnt, float* __restrict__ xyz,
+                                                         int32_t* __restrict__ counts, long long cap) {
+    __shared__ int lds4[4];
+    const int b = blockIdx.y, z = blockIdx.x, D = gridDim.x;
+    int part = 0;
+    for (int j = threadIdx.x; j < z; j += kThreads) part += plane_cnt[b * D + j];
+    int offset;
+    block_excl_scan(part, &offset, lds4);
+    const uint32_t* mp = mask + (size_t)(b * D + z) * wpp;
+    float* ob = xyz + (size_t)b * (size_t)cap * 3;
+    const float fz = (float)z;
+#pragma unroll 1
+    for (int base = 0; base < wpp; base += kThreads) {
+        const int w = base + threadIdx.x;
+        uint32_t bits = w < wpp ? mp[w] : 0u;
+        int total;
+        int pos = offset + block_excl_scan(__popc(bits), &total, lds4);
+        while (bits) {
+            const int vi = w * 32 + __ffs(bits) - 1;
+            bits &= bits - 1;
+            if (pos < cap) {
+                ob[(size_t)pos * 3 + 0] = fz;
+                ob[(size_t)pos * 3 + 1] = (float)(vi / W);
+                ob[(size_t)pos * 3 + 2] = (float)(vi % W);
+            }
+            ++pos;
+        }
+        offset += total;
+    }
+    if (z == D - 1 && threadIdx.x == 0) counts[b] = offset;
+}
+
 // ---- focal loss ----------------------------------------------------------------------------
 constexpr int kFocalBlocks = 1024;  // fixed: the reduction tree is identical on every device
 
@@ -460,9 +506,29 @@ PCC_API int pcc_voxelize(pcc_ctx* ctx, const int32_t* pts, const int32_t* block_
     return PCC_OK;
 }
 
+// scratch of the thresholding calls: the chunk counts of pcc_threshold_compact, or -- when the last layer delivers the occupancy
+// bits (pcc_thr_fuse) -- [B * D plane counts, padded to 4 ints][B * ceil(D*H*W / 32) mask words]; sized for either
 PCC_API size_t pcc_threshold_scratch_ints(int32_t B, int32_t D, int32_t H, int32_t W) {
     const size_t nvox = (size_t)D * H * W;
-    return (size_t)B * ((nvox + kChunk - 1) / kChunk);
+    const size_t chunks = (size_t)B * ((nvox + kChunk - 1) / kChunk);
+    const size_t fused = (((size_t)B * D + 3) & ~(size_t)3) + (size_t)B * ((nvox + 31) / 32);
+    return chunks > fused ? chunks : fused;
+}
+
+uint32_t* pcc_threshold_mask_of(int32_t* scratch, int32_t B, int32_t D) {
+    return reinterpret_cast<uint32_t*>(scratch + (((size_t)B * D + 3) & ~(size_t)3));
+}
+
+int pcc_threshold_from_mask(pcc_ctx* ctx, int32_t B, int32_t D, int32_t H, int32_t W, float* xyz, int32_t* counts, int64_t cap,
+                            int32_t* scratch, hipStream_t st) {
+    PCC_REQUIRE(ctx && xyz && counts && scratch && B > 0 && B <= 65535 && ((size_t)H * W) % 32 == 0 && cap >= 0,
+                "pcc_threshold_from_mask: bad argument");
+    const int wpp = (int)((size_t)H * W / 32);
+    const uint32_t* mask = pcc_threshold_mask_of(scratch, B, D);
+    hipLaunchKernelGGL(k_mask_count, dim3(D, B), dim3(kThreads), 0, st, mask, wpp, scratch);
+    hipLaunchKernelGGL(k_mask_write, dim3(D, B), dim3(kThreads), 0, st, mask, wpp, W, scratch, xyz, counts, (long long)cap);
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
 }
 
 PCC_API int pcc_threshold_compact(pcc_ctx* ctx, const float* x, int32_t B, int32_t D, int32_t H, int32_t W,

@@ -227,9 +227,23 @@ PCC_API int pcc_network_out_dims(int32_t transform, int32_t filters, int32_t D, 
     return PCC_OK;
 }
 
+static int network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x, int32_t N,
+                           int32_t D, int32_t H, int32_t W, float* y, void* workspace, size_t workspace_bytes,
+                           int32_t layer_flags, int32_t final_flags, const pcc_thr_fuse* fuse, bool* fused, void* stream);
+
 PCC_API int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x, int32_t N,
                                 int32_t D, int32_t H, int32_t W, float* y, void* workspace, size_t workspace_bytes,
                                 int32_t layer_flags, int32_t final_flags, void* stream) {
+    return network_forward(ctx, transform, filters, blob, x, N, D, H, W, y, workspace, workspace_bytes, layer_flags, final_flags,
+                           nullptr, nullptr, stream);
+}
+
+// fuse (synthesis transforms whose last layer is the 16 -> 1 transposed conv): that layer also writes the occupancy bits of
+// the fixed-threshold extraction; *fused reports whether it did.
+static int network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, const float* blob, const float* x, int32_t N,
+                           int32_t D, int32_t H, int32_t W, float* y, void* workspace, size_t workspace_bytes,
+                           int32_t layer_flags, int32_t final_flags, const pcc_thr_fuse* fuse, bool* fused, void* stream) {
+    if (fused) *fused = false;
     std::vector<LayerSpec> v;
     std::vector<LayerImage> im;
     int c0;
@@ -314,8 +328,15 @@ PCC_API int pcc_network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters
             }
             PCC_CHECK_HIP(hipEventRecord(prof->ev[prof->used], st));
         }
-        const int rc = pcc_conv3d(ctx, &d, in, blob + im[i].w, im[i].pk_floats ? blob + im[i].pk : nullptr,
-                                  L.bias ? blob + im[i].b : nullptr, L.res == 2 ? t1 : nullptr, out, stream);
+        int rc;
+        if (last && fuse && im[i].pk_floats && d.impl == PCC_IMPL_AUTO && pcc_conv_mfma_supported(&d) == 1) {
+            PCC_CHECK_HIP(hipSetDevice(ctx->device));
+            rc = pcc_conv3d_mfma_thr(ctx, &d, in, blob + im[i].pk, L.bias ? blob + im[i].b : nullptr, L.res == 2 ? t1 : nullptr, out,
+                                     fuse, fused, st);
+        } else {
+            rc = pcc_conv3d(ctx, &d, in, blob + im[i].w, im[i].pk_floats ? blob + im[i].pk : nullptr,
+                            L.bias ? blob + im[i].b : nullptr, L.res == 2 ? t1 : nullptr, out, stream);
+        }
         if (rc != PCC_OK) return rc;
         if (timed) { PCC_CHECK_HIP(hipEventRecord(prof->ev[prof->used + 1], st)); prof->used += 2; }
         out_dims(L, D, H, W);
@@ -454,11 +475,16 @@ PCC_API int pcc_codec_encode(pcc_ctx* ctx, const pcc_codec_desc* c, const float*
     // everything the range coder needs is final here: the caller's copy stream / host coder can start while the synthesis
     // transform (most of the work) is still being enqueued and executed
     if (symbols_ready) PCC_CHECK_HIP(hipEventRecord((hipEvent_t)symbols_ready, (hipStream_t)stream));
-    rc = pcc_network_forward(ctx, c->synthesis, F, c->w_synthesis, y_hat, N, D / 8, H / 8, W / 8, x_hat, workspace,
-                             workspace_bytes, layer_flags, final_flags, stream);
+    // fixed-threshold policy (model_opt.py:27-31): the encoder-side point lists in the same call; the encoder clips (:202).  The
+    // last synthesis layer writes the occupancy bits itself where it can (pcc_thr_fuse); otherwise x_hat is thresholded here.
+    PCC_REQUIRE(!thr || (xyz && counts && scratch), "pcc_codec_encode: thr given but xyz / counts / scratch is NULL");
+    static const bool no_fuse = getenv("PCC_NO_THR_FUSE") != nullptr;
+    const pcc_thr_fuse fuse = {thr, 1, thr ? pcc_threshold_mask_of(scratch, N, D) : nullptr};
+    bool fused = false;
+    rc = network_forward(ctx, c->synthesis, F, c->w_synthesis, y_hat, N, D / 8, H / 8, W / 8, x_hat, workspace,
+                         workspace_bytes, layer_flags, final_flags, thr && !no_fuse ? &fuse : nullptr, &fused, stream);
     if (rc != PCC_OK || !thr) return rc;
-    // fixed-threshold policy (model_opt.py:27-31): the encoder-side point lists in the same call; the encoder clips (:202)
-    PCC_REQUIRE(xyz && counts && scratch, "pcc_codec_encode: thr given but xyz / counts / scratch is NULL");
+    if (fused) return pcc_threshold_from_mask(ctx, N, D, H, W, xyz, counts, cap, scratch, (hipStream_t)stream);
     return pcc_threshold_compact(ctx, x_hat, N, D, H, W, thr, 1, xyz, counts, cap, scratch, stream);
 }
 
@@ -508,10 +534,13 @@ PCC_API int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, int32_t
     }
     rc = pcc_dequantize(ctx, ysym, c->version == 1 ? c->medians : nullptr, y_hat, ny, F, stream);
     if (rc != PCC_OK) return rc;
-    rc = pcc_network_forward(ctx, c->synthesis, F, c->w_synthesis, y_hat, N, D / 8, H / 8, W / 8, x_hat, workspace,
-                             workspace_bytes, layer_flags, 0, stream);
+    PCC_REQUIRE(!thr || (xyz && counts && scratch), "pcc_codec_decode_main: thr given but xyz / counts / scratch is NULL");
+    static const bool no_fuse = getenv("PCC_NO_THR_FUSE") != nullptr;
+    const pcc_thr_fuse fuse = {thr, 0 /* the decoder does not clip, model_types.py:232-233 */, thr ? pcc_threshold_mask_of(scratch, N, D) : nullptr};
+    bool fused = false;
+    rc = network_forward(ctx, c->synthesis, F, c->w_synthesis, y_hat, N, D / 8, H / 8, W / 8, x_hat, workspace,
+                         workspace_bytes, layer_flags, 0, thr && !no_fuse ? &fuse : nullptr, &fused, stream);
     if (rc != PCC_OK || !thr) return rc;
-    PCC_REQUIRE(xyz && counts && scratch, "pcc_codec_decode_main: thr given but xyz / counts / scratch is NULL");
-    return pcc_threshold_compact(ctx, x_hat, N, D, H, W, thr, 0 /* the decoder does not clip, model_types.py:232-233 */, xyz, counts,
-                                 cap, scratch, stream);
+    if (fused) return pcc_threshold_from_mask(ctx, N, D, H, W, xyz, counts, cap, scratch, (hipStream_t)stream);
+    return pcc_threshold_compact(ctx, x_hat, N, D, H, W, thr, 0, xyz, counts, cap, scratch, stream);
 }

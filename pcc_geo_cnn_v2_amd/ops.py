@@ -317,7 +317,7 @@ def symbols_unpack(ctx, src, ndhwc_shape, channels_first):
     return out
 
 
-def codec_encode(ctx, desc, x, thr=None, cap=None, symbols_ready=None, staging=None):
+def codec_encode(ctx, desc, x, thr=None, cap=None, symbols_ready=None, staging=None, scratch=None):
     """The GPU part of compress() (src/model_types.py:289-293 / :379-388) for a batch of blocks in ONE ABI call.
     x: (N,D,H,W) float32.  Returns dict of device tensors (NDHWC); with `thr` (N,) float32 also the encoder-side point
     lists xyz / counts of the clipped x_hat (fixed-threshold policy).  symbols_ready: a torch.cuda.Event that has been
@@ -332,12 +332,15 @@ def codec_encode(ctx, desc, x, thr=None, cap=None, symbols_ready=None, staging=N
     t = dict(y=f32(*ys), symbols=i32(*ys), y_hat=f32(*ys), x_hat=f32(N, D, H, W))
     if desc.version == 2:
         t.update(z=f32(*zs), z_symbols=i32(*zs), z_hat=f32(*zs), sigma_hat=f32(*ys), indexes=i32(*ys))
-    xyz = counts = scratch = None
+    xyz = counts = None
     cap = D * H * W if cap is None else int(cap)
     if thr is not None:
         assert thr.dtype == torch.float32 and thr.numel() == N
         xyz, counts = torch.empty((N, cap, 3), dtype=torch.float32, device=dev), torch.empty((N,), dtype=torch.int32, device=dev)
-        scratch = torch.empty((L.lib().pcc_threshold_scratch_ints(N, D, H, W),), dtype=torch.int32, device=dev)
+        n_scratch = L.lib().pcc_threshold_scratch_ints(N, D, H, W)
+        if scratch is None:
+            scratch = torch.empty((n_scratch,), dtype=torch.int32, device=dev)
+        assert scratch.dtype == torch.int32 and scratch.numel() >= n_scratch and scratch.device == dev
         t.update(xyz=xyz, counts=counts)
     ws = ctx.workspace(L.lib().pcc_codec_workspace_bytes(C.byref(desc), N, D, H, W))
     L.check(L.lib().pcc_codec_encode(ctx.handle, C.byref(desc), _ptr(x), N, D, H, W, _ptr(t['y']), _ptr(t.get('z')),
@@ -388,7 +391,7 @@ def codec_decode_hyper(ctx, desc, zsym, dhw, packed=None, channels_first=True, i
     return t
 
 
-def codec_decode_main(ctx, desc, ysym, dhw, thr=None, cap=None, packed=None, channels_first=True):
+def codec_decode_main(ctx, desc, ysym, dhw, thr=None, cap=None, packed=None, channels_first=True, scratch=None):
     """y symbols -> y_hat -> x_hat (+ thresholding and compaction when `thr` (N,) float32 is given), one ABI call
     (src/model_types.py:305-307 / :407-408, :232-234).  packed: instead of ysym, the stream-order symbols on the device (see
     codec_decode_hyper); the int32 tensor comes back as 'symbols'."""
@@ -404,13 +407,16 @@ def codec_decode_main(ctx, desc, ysym, dhw, thr=None, cap=None, packed=None, cha
     assert ysym.dtype == torch.int32 and ysym.is_contiguous() and tuple(ysym.shape) == ys
     t = dict(y_hat=torch.empty(ys, dtype=torch.float32, device=dev), x_hat=torch.empty((N, D, H, W), dtype=torch.float32, device=dev),
              symbols=ysym)
-    xyz = counts = scratch = None
+    xyz = counts = None
     cap = D * H * W if cap is None else int(cap)
     if thr is not None:
         assert thr.dtype == torch.float32 and thr.numel() == N
         xyz = torch.empty((N, cap, 3), dtype=torch.float32, device=dev)
         counts = torch.empty((N,), dtype=torch.int32, device=dev)
-        scratch = torch.empty((L.lib().pcc_threshold_scratch_ints(N, D, H, W),), dtype=torch.int32, device=dev)
+        n_scratch = L.lib().pcc_threshold_scratch_ints(N, D, H, W)
+        if scratch is None:
+            scratch = torch.empty((n_scratch,), dtype=torch.int32, device=dev)
+        assert scratch.dtype == torch.int32 and scratch.numel() >= n_scratch and scratch.device == dev
         t.update(xyz=xyz, counts=counts)
     ws = ctx.workspace(L.lib().pcc_codec_workspace_bytes(C.byref(desc), N, D, H, W))
     L.check(L.lib().pcc_codec_decode_main(ctx.handle, C.byref(desc), _ptr(ysym), N, D, H, W, _ptr(t['y_hat']), _ptr(t['x_hat']),

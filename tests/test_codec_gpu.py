@@ -398,3 +398,42 @@ def test_symbols_pack_unpack_is_the_stream_order_permutation(ctx, shape, dtype, 
     assert int(tmax.max()) == int(src.abs().max()) and int(tmax.min()) >= 0
     back = ops.symbols_unpack(ctx, out, shape, cf)
     assert torch.equal(back, src)
+
+
+@pytest.mark.parametrize('res,batch', [(64, 32), (64, 3), (16, 2), (32, 5)])
+def test_last_layer_writes_the_occupancy_bits_of_the_fixed_threshold(ctx, res, batch):
+    """Round 3: the 16 -> 1 last synthesis layer folds clip + `x_hat > thr` (model_types.py:202,209 encoder, :232-234 decoder:
+    no clip) into its epilogue as one bit per voxel and the point lists are compacted from those bits; both must equal what the
+    stand-alone threshold kernels give on the x_hat the same call returns -- and the bits must really be there (32 x 32-column
+    kernel at batch 32, 16 x 16-column kernel otherwise)."""
+    m = ModelConfigType['c3p'].build(batch_size=batch)
+    m.compress([1, 1, res, res, res])
+    m.set_weights(scaled_weights(m, 2.2))
+    mc = m._ctx(ctx)
+    x = (torch.rand((batch, res, res, res), generator=torch.Generator().manual_seed(11)) < 0.05).float().to(ctx.device)
+    thr = torch.linspace(0.35, 0.65, batch, dtype=torch.float32).to(ctx.device)
+    nvox = res ** 3
+    n_scratch = L.lib().pcc_threshold_scratch_ints(batch, res, res, res)
+    off = (batch * res + 3) // 4 * 4
+    weights = (1 << torch.arange(32, dtype=torch.int64, device=ctx.device))
+
+    def check(t, scratch, clip):
+        xh = t['x_hat']
+        ref_xyz, ref_cnt = ops.threshold_compact(mc, xh, thr, clip=clip)
+        assert torch.equal(t['counts'], ref_cnt) and int(ref_cnt.min()) > 0
+        for b in range(batch):
+            n = int(ref_cnt[b])
+            assert torch.equal(t['xyz'][b, :n], ref_xyz[b, :n])
+        v = xh.clamp(0, 1) if clip else xh
+        bits = (v > thr[:, None, None, None]).reshape(batch, nvox // 32, 32).to(torch.int64)
+        words = (bits * weights).sum(-1)
+        words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).reshape(-1)
+        assert torch.equal(scratch[off:off + batch * nvox // 32], words), 'the last layer did not write the occupancy bits'
+
+    s1 = torch.full((n_scratch,), 0x55555555, dtype=torch.int32, device=ctx.device)
+    e = ops.codec_encode(mc, m._codec(mc), x, thr, scratch=s1)
+    check(e, s1, True)
+    s2 = torch.full((n_scratch,), 0x55555555, dtype=torch.int32, device=ctx.device)
+    d = ops.codec_decode_main(mc, m._codec(mc), e['symbols'], [res] * 3, thr, scratch=s2)
+    assert torch.equal(d['x_hat'], e['x_hat'])
+    check(d, s2, False)
