@@ -1243,10 +1243,12 @@ struct Cout1M {
     static constexpr int LYX = TYX + 2;                 // haloed plane edge
     static constexpr int NTILE = (LYX * LYX + 15) / 16; // N-tiles of 16 voxels: 21 (324 voxels) / 73 (1156)
     static constexpr int NU = NTILE * 16;
-    static constexpr int RS = NU + 4;                   // row pitch of P in floats: 4 * RS = 16 (mod 32) -> the four channel quads of a
-                                                        // ds_write_b32 fall on two bank halves (2 cycles, the minimum for 64 lanes) instead of one
+    static constexpr int RS = NU + 20;                  // row pitch of P in floats: 4 * RS = 16 (mod 32) -> the four channel quads of a
+                                                        // ds_write_b32 fall on two bank halves (2 cycles, the minimum for 64 lanes) instead of one;
+                                                        // columns [NU + 4, NU + 20) of a row take the writes of the N-tiles past the plane (the last,
+                                                        // partial round of tiles): every wave writes every round, no branch in the MFMA stream
     static_assert((4 * RS) % 32 == 16, "row pitch");
-    static constexpr int LDS_BYTES = 32 * RS * 4;       // 32 tap rows: 27 + the zero rows of the second M tile (43.5 KB / 146.5 KB)
+    static constexpr int LDS_BYTES = 32 * RS * 4;       // 32 tap rows: 27 + the zero rows of the second M tile (45.5 KB / 148.5 KB)
     static constexpr int PER_WAVE = (NTILE + NW - 1) / NW;    // N-tiles per wave (6,5,5,5 / 5 x9, 4 x7)
 };
 
@@ -1286,7 +1288,7 @@ __global__ void __launch_bounds__((Cout1M<T>::NT)) conv_cout1_mfma_kernel(ConvAr
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
         const bool ok = nt < C::NTILE && u < C::LYX * C::LYX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         voff[k] = ok ? (unsigned)((gy * a.W + gx) * 16 + cq * 4) * (IN16 ? 2u : 4u) : kOOB;
-        uidx[k] = u;
+        uidx[k] = nt < C::NTILE ? u : C::NU + 4 + v;
     }
     const unsigned plane_bytes = (unsigned)a.H * a.W * (IN16 ? 32u : 64u);
     const unsigned char* inb = (const unsigned char*)a.in + (size_t)n * a.D * plane_bytes;
@@ -1336,69 +1338,132 @@ __global__ void __launch_bounds__((Cout1M<T>::NT)) conv_cout1_mfma_kernel(ConvAr
         }
     };
 
-    f32x4 nxt[C::PER_WAVE];
+#ifndef PCC_C1_PROBE
+#define PCC_C1_PROBE 0      // timing probes (tools/build_variant.sh): 1 no P writes, 2 no gather reads, 4 no MFMA, 8 no barriers, 16 no plane loads
+#endif
+    // ---- (1) P[tap][voxel] = W x in, one N-tile (16 voxels) at a time: d0 = taps 0..15, d1 = taps 16..31 of tile k
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};      // first k-slot starts from the inline constant 0: no zero-init pass (VALU costs MFMA time)
+    f32x4 x[C::PER_WAVE], d0[C::PER_WAVE], d1[C::PER_WAVE];
+    auto taps = [&](auto k0_tag, auto k1_tag) __attribute__((always_inline)) {      // tiles [K0, K1)
+        constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+        if constexpr ((PCC_C1_PROBE & 4) != 0) {
 #pragma unroll
-    for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = load_in(voff[k], (unsigned)p0 * plane_bytes);
-    float accA = 0.f, accB = 0.f, accC = 0.f;   // outputs z = p+1, p, p-1
-
-#pragma unroll 1
-    for (int p = p0; p <= p1; ++p) {
-        f32x4 cur[C::PER_WAVE];
+            for (int k = K0; k < K1; ++k) { d0[k] = x[k]; d1[k] = x[k] * wA1; }
+        } else if constexpr (IN16) {
 #pragma unroll
-        for (int k = 0; k < C::PER_WAVE; ++k) cur[k] = nxt[k];
-        if (p + 1 <= p1) {
-#pragma unroll
-            for (int k = 0; k < C::PER_WAVE; ++k) nxt[k] = load_in(voff[k], (unsigned)(p + 1) * plane_bytes);
-        }
-        // ---- (1) P = W x in for the haloed plane p
-        f32x4 d0[C::PER_WAVE], d1[C::PER_WAVE];
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};      // first k-slot starts from the inline constant 0: no zero-init pass (VALU costs MFMA time)
-        if constexpr (IN16) {
-#pragma unroll
-            for (int k = 0; k < C::PER_WAVE; ++k) {
-                const u32x4 cb = __builtin_bit_cast(u32x4, cur[k]);
+            for (int k = K0; k < K1; ++k) {
+                const u32x4 cb = __builtin_bit_cast(u32x4, x[k]);
                 const h16x4 bh = __builtin_bit_cast(h16x4, (u32x2){cb[0], cb[1]});
                 d0[k] = __builtin_amdgcn_mfma_f32_16x16x16f16(wA0h, bh, zero4, 0, 0, 0);
                 d1[k] = __builtin_amdgcn_mfma_f32_16x16x16f16(wA1h, bh, zero4, 0, 0, 0);
             }
         } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < C::PER_WAVE; ++k) {
-                d0[k] = mfma16(wA0[j], cur[k][j], j == 0 ? zero4 : d0[k]);
-                d1[k] = mfma16(wA1[j], cur[k][j], j == 0 ? zero4 : d1[k]);
-            }
-        }
-        // all 32 tap rows are written (rows 27..31 are never read): no lane-dependent branch around the ds_writes
-#pragma unroll
-        for (int k = 0; k < C::PER_WAVE; ++k) {
-            if (C::NW * k + C::NW - 1 < C::NTILE || wave + C::NW * k < C::NTILE) {      // (compile-time for all but the last, partial round of tiles)
-                float* pw = P + uidx[k] + 4 * cq * C::RS;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pw[r * C::RS] = d0[k][r];
-                    pw[(16 + r) * C::RS] = d1[k][r];
+                for (int k = K0; k < K1; ++k) {
+                    d0[k] = mfma16(wA0[j], x[k][j], j == 0 ? zero4 : d0[k]);
+                    d1[k] = mfma16(wA1[j], x[k][j], j == 0 ? zero4 : d1[k]);
                 }
+        }
+    };
+    auto fetch = [&](auto k0_tag, auto k1_tag, int plane) __attribute__((always_inline)) {
+        constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+        const unsigned soff = (unsigned)(((PCC_C1_PROBE & 16) != 0) ? p0 : min(plane, p1)) * plane_bytes;     // (clamped: a plane past the slab is loaded, never used)
+#pragma unroll
+        for (int k = K0; k < K1; ++k) x[k] = load_in(voff[k], soff);
+    };
+    // all 32 tap rows are written (rows 27..31 are never read), tiles past the plane go to the pad columns: no branch around the ds_writes
+    auto store = [&](auto k0_tag, auto k1_tag) __attribute__((always_inline)) {
+        constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+#pragma unroll
+        for (int k = K0; k < K1; ++k) {
+            if constexpr ((PCC_C1_PROBE & 1) != 0) { if (d0[k][0] == 1.2345f && d1[k][1] == 5.4321f) P[uidx[k]] = d0[k][2]; continue; }
+            float* pw = P + uidx[k] + 4 * cq * C::RS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pw[r * C::RS] = d0[k][r];
+                pw[(16 + r) * C::RS] = d1[k][r];
             }
         }
-        __syncthreads();
-        // ---- (2) gather: plane p is tap kz = 0 of output p+1, kz = 1 of output p, kz = 2 of output p-1
+    };
+    // ---- (2) gather: the plane in P is tap kz = 0 of output p+1, kz = 1 of output p, kz = 2 of output p-1
+    float accA = 0.f, accB = 0.f, accC = 0.f;   // outputs z = p+1, p, p-1
+    auto gather = [&]() __attribute__((always_inline)) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const float* q = pcol + ky * C::LYX + kx;
+                if constexpr ((PCC_C1_PROBE & 2) != 0) { if (ky + kx > 0) continue; }
                 s0 += q[(0 * 9 + ky * 3 + kx) * C::RS];
                 s1 += q[(1 * 9 + ky * 3 + kx) * C::RS];
                 s2 += q[(2 * 9 + ky * 3 + kx) * C::RS];
             }
         accA += s0; accB += s1; accC += s2;
-        if (p - 1 >= zb) finish(accC, p - 1);          // (p - 1 < ze always: p <= ze)
+    };
+    auto sync = [&]() __attribute__((always_inline)) { if constexpr ((PCC_C1_PROBE & 8) == 0) __syncthreads(); };
+
+    // Software pipeline (round 3; round 2 ran load -> MFMA -> LDS write -> barrier -> gather -> barrier strictly in turn, with the
+    // matrix pipe idle 45 % of the time).  The N-tiles of a wave are split into a front group [0, KB) and a back group [KB, PER_WAVE).
+    // At the top of iteration q:  P = tap planes of plane q;  d[front] = tap planes of plane q+1 (in flight);  d[back] = stale
+    // (plane q, already in P);  x[back] = inputs of plane q+1;  x[front] = inputs of plane q+2 (loads in flight).
+    //   phase A:  back-group MFMAs of plane q+1  ||  the 27 LDS reads of the gather of plane q;  finish(q-1);  refill x[back]
+    //   barrier   (every wave has read P)
+    //   phase B:  per front tile: write its plane-(q+1) rows, then its MFMAs of plane q+2 into the same registers;  refill x[front];
+    //             the back group's rows are written between those MFMAs
+    //   barrier   (P = plane q+1)
+    // so the matrix pipe always has work while LDS is read or written, and every input tile is loaded one iteration before use.
+    constexpr int KB = C::PER_WAVE - 2;
+    using I0 = std::integral_constant<int, 0>;
+    using IB = std::integral_constant<int, KB>;
+    using IE = std::integral_constant<int, C::PER_WAVE>;
+    fetch(I0{}, IE{}, p0);
+    taps(I0{}, IE{});
+    store(I0{}, IE{});
+    fetch(I0{}, IB{}, p0 + 1);
+    sync();
+    taps(I0{}, IB{});
+    fetch(I0{}, IB{}, p0 + 2);
+    fetch(IB{}, IE{}, p0 + 1);
+#pragma unroll 1
+    for (int q = p0; q < p1; ++q) {
+        // ---- phase A
+        taps(IB{}, IE{});
+        gather();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
+        }
+        fetch(IB{}, IE{}, q + 2);
+        if (q - 1 >= zb) finish(accC, q - 1);          // (q - 1 < ze always: q <= ze)
         accC = accB; accB = accA; accA = 0.f;
-        __syncthreads();
+        sync();
+        // ---- phase B
+        store(I0{}, IB{});
+        taps(I0{}, IB{});
+        store(IB{}, IE{});
+        if constexpr (!IN16 && (PCC_C1_PROBE & 5) == 0) {
+            // a front tile's 8 row writes go out before its first MFMA pair overwrites the registers; the remaining MFMAs carry the back rows
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 8, 0);  // 8 DS writes
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA (j = 0 of tile k)
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+        }
+        fetch(I0{}, IB{}, q + 3);
+        sync();
     }
+    gather();                                          // plane p1
+    if (p1 - 1 >= zb) finish(accC, p1 - 1);
+    accC = accB; accB = accA; accA = 0.f;
     if (ze == a.D) finish(accC, a.D - 1);              // the last plane of the volume has no plane behind it
 }
 
