@@ -174,10 +174,14 @@ class CompressionModel:
         assert len(x_shape) == 5
         return tuple(x_shape[2:5]) if self.data_format == 'channels_first' else tuple(x_shape[1:4])
 
-    def _side_stream(self, ctx):
-        if not hasattr(self, '_copy_stream'):
-            self._copy_stream = torch.cuda.Stream(ctx.device)
-        return self._copy_stream
+    def _side_stream(self, ctx, which='_copy_stream'):
+        """Copy streams beside the main one.  Work on one stream runs in order, so copies with different dependencies get
+        different streams: '_copy_stream' (encoder symbols and decoded points to the host: each waits for an event of the main
+        stream), '_up_stream' (decoder symbols to the device: no GPU-side dependency, they run as soon as the host has decoded
+        them), '_idx_stream' (the decoder's CDF-row indexes to the host)."""
+        if not hasattr(self, which):
+            setattr(self, which, torch.cuda.Stream(ctx.device))
+        return getattr(self, which)
 
     def _staging(self, ctx, slot, B, y_dhw, z_dhw=None):
         """Per pipeline slot: the device + pinned staging buffers of one encode (ops.SymbolStaging), cached."""
@@ -309,10 +313,18 @@ class CompressionModel:
 
     def _symbols_to_device(self, ctx, sym_host, release):
         """Stream-order host symbols -> the device, as they are (one host->device copy of the narrow integers: half the PCIe
-        bytes of int32).  The library unpacks them into the int32 (B,D,H,W,C) tensor inside the decoder call
-        (pcc_symbol_io); the per-layer path calls ops.symbols_unpack."""
-        dev = sym_host.to(ctx.device, non_blocking=True)
-        release(torch.cuda.current_stream(ctx.device))
+        bytes of int32).  The copy runs on the SIDE stream -- a copy on the main stream would hold back every kernel queued
+        behind it for its 20-60 us, and the decoder calls of a chunk are enqueued long before the GPU gets to them -- on a
+        stream of their own (nothing there ever waits for the GPU), and the main stream only waits for the copy's event.  The library unpacks the symbols into the int32 (B,D,H,W,C) tensor inside the
+        decoder call (pcc_symbol_io); the per-layer path calls ops.symbols_unpack."""
+        main, side = torch.cuda.current_stream(ctx.device), self._side_stream(ctx, '_up_stream')
+        with torch.cuda.stream(side):
+            dev = sym_host.to(ctx.device, non_blocking=True)
+            release(side)
+            arrived = torch.cuda.Event()
+            arrived.record(side)
+        main.wait_event(arrived)
+        dev.record_stream(main)
         return dev
 
     def _unpack(self, ctx, packed, dhw):
@@ -924,9 +936,15 @@ class CompressionModelV2(CompressionModel):
             ops.symbols_pack(ctx, idx, cf, idx_s.data_ptr(), idx_s.element_size())
         # (the host reads idx_h synchronously in phase b, long before the ring comes round: no release event needed)
         idx_h, _ = self._pinned.ring('dec_idx', idx_s.shape, row_t)
-        idx_h.copy_(idx_s, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(ctx.device))
+        packed = torch.cuda.Event()
+        packed.record(torch.cuda.current_stream(ctx.device))
+        side = self._side_stream(ctx, '_idx_stream')
+        with torch.cuda.stream(side):               # (not on the main stream: the copy would delay the kernels queued behind it)
+            side.wait_event(packed)
+            idx_s.record_stream(side)
+            idx_h.copy_(idx_s, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
         return dict(strings=strings, idx_h=idx_h, ev=ev, z_hat=z_hat, sigma=sigma, idx=idx, zsym_h=zsym_h)
 
     def _decode_phase_b(self, ctx, st, dhw, debug, thr=None):
