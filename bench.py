@@ -248,9 +248,11 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     ctx = ops.get_context(device)
+    # host threads follow the cores the container may really use (its CPU quota), not the cores it can see
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), ops.usable_cores() // max(world, 1))))
 
     # host range-coder threads: share the node's cores between the ranks
-    coder_threads = args.coder_threads or max(8, (os.cpu_count() or 8) // max(world, 1))
+    coder_threads = args.coder_threads or max(8, ops.usable_cores() // max(world, 1))     # (cgroup-quota aware: a 16-CPU container that shows 256 cores gets throttled by 256 threads)
     model = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads, precision=args.precision)
     model.compress([1, 1, RES, RES, RES])
     w = synthetic_weights(model)
@@ -294,11 +296,17 @@ def main():
     from pcc_geo_cnn_v2_amd import _lib as L
     DOM_LAYER = 8
     ops.profile_select(ctx, L.PCC_NET_SYNTHESIS_PROGRESSIVE_V2, DOM_LAYER)
+    if os.environ.get('PCC_BENCH_NOGC'):
+        import gc
+        gc.collect(); gc.disable()
     barrier()
+    dev_allocs0 = torch.cuda.memory_stats(device).get('num_device_alloc', 0)
     t0 = time.perf_counter()
     n_blocks, n_bytes, n_pts = run(args.steps)
     barrier()
+    dev_allocs = torch.cuda.memory_stats(device).get('num_device_alloc', 0) - dev_allocs0      # hipMalloc calls inside the timed region (each one stalls the queue)
     if os.environ.get('PCC_BENCH_STAMPS'):      # arrival spacing of the chunks (ms), for pipeline debugging
+        print('device allocations inside the timed region:', dev_allocs, file=sys.stderr)
         print('stamps', ' '.join(f'{1e3 * (b - a):.2f}' for a, b in zip(stamps[:-1], stamps[1:])), file=sys.stderr)
     t1 = time.perf_counter()
     elapsed = t1 - t0

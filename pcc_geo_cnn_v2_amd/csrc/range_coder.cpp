@@ -216,10 +216,12 @@ int decode_stream(const pcc_cdf_table& t, const uint8_t* str, size_t len, const 
 }
 
 // ------------------------------------------------------------------------------------------
-// persistent pool: parallel_for(n, fn) runs fn(i) for i in [0,n) on up to `threads` workers
+// persistent pool: parallel_for(n, fn) runs fn(i) for i in [0,n) on up to `threads` workers.  One pool per CALLING thread
+// (thread_local): a host that range-encodes one chunk on a helper thread while it range-decodes another on the main thread
+// gets two sets of workers instead of one lock.
 class Pool {
   public:
-    static Pool& get() { static Pool p; return p; }
+    static Pool& get() { static thread_local Pool p; return p; }
     void parallel_for(int n, int threads, const std::function<void(int)>& fn) {
         if (n <= 0) return;
         const int hw = (int)std::max(1u, std::thread::hardware_concurrency());

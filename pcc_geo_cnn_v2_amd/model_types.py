@@ -15,6 +15,8 @@ MI355X-first differences (results identical):
 import logging
 import os
 import pprint
+import sys
+import time
 from enum import Enum
 
 import numpy as np
@@ -87,6 +89,22 @@ def select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics, points, r
         cand_metrics[m] = met
     return [{'idx': m, 'metrics': met, 'x_hat_list': x_hat_list[m], 'blocks_depart': placed[m], 'blocks_full': clouds[m]}
             for _, m, met in rank_candidates(opt_metrics, cand_metrics, opt_groups)]
+
+
+def _usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container that sees 256 cores may
+    be throttled to 16 CPUs' worth of time per period -- running more threads than that gets the whole process paused)."""
+    return ops.usable_cores()
+
+
+class _Immediate:
+    """A future-like wrapper that runs its function when the result is asked for (the caller's thread)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def result(self):
+        return self.fn()
 
 
 def _host_dtypes():
@@ -255,7 +273,7 @@ class CompressionModel:
         from .model_opt import HostSearchPool
         # default: the cores this process may run on, at most 64 (measured on a 256-thread box whose container gets far fewer: 64
         # workers 17.5 s per 190-block cloud with d2 metrics, 128 workers 23.6 s -- the KD-tree work is host-bound)
-        usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        usable = _usable_cores() * 4          # (KD-tree queries wait on memory: 64 workers on a 16-CPU quota measured best)
         want = max(1, min(n_jobs, self.search_threads or min(usable, 64)))
         pool = getattr(self, '_host_search_pool', None)
         if pool is None or len(pool.procs) < want:
@@ -263,6 +281,13 @@ class CompressionModel:
                 pool.close()
             self._host_search_pool = pool = HostSearchPool(want)
         return pool
+
+    def _coder_thread(self):
+        """One helper thread for host range-coder work that may overlap the calling thread's (roundtrip_stream)."""
+        if getattr(self, '_coder_pool', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._coder_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='pcc-coder')
+        return self._coder_pool
 
     def _thr_tensor(self, ctx, thr_idx):
         """float32 thresholds of the blocks of a chunk as a device tensor."""
@@ -606,7 +631,7 @@ class CompressionModel:
 
         def stage_a(item):
             enc, dhw, B = item
-            strings = enc['finish']()
+            strings = enc['strings'].result()
             st = self._decode_phase_a(ctx, strings, dhw)
             q_b.append((strings, enc['counts'], st, dhw, B))
             if len(q_b) > 1:
@@ -615,16 +640,30 @@ class CompressionModel:
         # The GPU work of chunk k+1 (compress graph) is enqueued BEFORE the host waits for the symbols of chunk k: the device
         # queue then always holds at least one more compress graph than the host coder needs to stay ahead of, so a slow or
         # noisy host does not drain it.  Pinned symbol buffers are per slot (three chunks can be between enqueue and coding).
+        # The range ENCODER of a chunk (wait for its symbols, code them) runs on a helper thread -- the coder is sequential per
+        # stream, so at 128^3 one chunk's y streams cost the host milliseconds -- while this thread range-DECODES an older chunk
+        # and feeds the GPU; the library calls release the GIL.
         q_a, k = [], 0
+        trace = os.environ.get('PCC_STAGE_TIMES')          # host time per pipeline stage and iteration (ms), to stderr
         for x in dense_chunks:
             B, dhw = x.shape[0], tuple(x.shape[1:4])
+            t0 = time.perf_counter()
             enc = self._encode_batch(ctx, x, False, thr=self._thr_tensor(ctx, [thr_idx] * B), slot=k % 3)
+            # (only when both coders fit the usable cores side by side: with 32 streams per call on a 16-core container the two
+            # would just take turns, with scheduler jitter on top -- measured: 7-12 ms hiccups in the 64^3 headline)
+            enc['strings'] = self._coder_thread().submit(enc['finish']) if 2 * B <= _usable_cores() else _Immediate(enc['finish'])
             k += 1
             q_a.append((enc, dhw, B))
+            t1 = time.perf_counter()
             if len(q_a) > 1:
                 stage_a(q_a.pop(0))
+            t2 = time.perf_counter()
             if len(q_g) > 1:
-                yield stage_g(q_g.pop(0))
+                out = stage_g(q_g.pop(0))
+                if trace:
+                    print(f'stage ms: enqueue {1e3 * (t1 - t0):.2f} decode+enqueue {1e3 * (t2 - t1):.2f} gather {1e3 * (time.perf_counter() - t2):.2f}',
+                          file=sys.stderr)
+                yield out
         while q_a:
             stage_a(q_a.pop(0))
         while q_b:

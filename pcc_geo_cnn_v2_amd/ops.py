@@ -4,6 +4,7 @@ PyTorch-ROCm is plumbing only: it owns device memory (tensors) and streams; ever
 a hand-written HIP kernel (or the host range coder) inside libpcc_geo_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -242,6 +243,24 @@ def codec_desc(ctx, version, filters, nets, medians=None, scale_table=None, roun
     d.scale_levels = 0 if scale_table is None else scale_table.numel()
     keep += [medians, scale_table]
     return d, keep
+
+
+def usable_cores():
+    """Cores this process may use: the affinity mask capped by the cgroup CPU quota (cgroup v2 cpu.max, v1 cfs_quota_us)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 _ITEM = {torch.uint8: 1, torch.int16: 2, torch.int32: 4}
