@@ -151,9 +151,10 @@ def cpu_baseline(model, w, blocks_np, budget_s=12.0):
         el = time.perf_counter() - t0
         if (el > budget_s and n >= 2) or n >= 1024:
             break
-    return dict(value=n / el, unit='blocks/s', cores=os.cpu_count(), threads_used=torch.get_num_threads(), kind='port',
-                note='cores = logical host cores of the box; threads_used = oneDNN intra-op threads, calibrated on one block '
-                     '(batch-1 convs stop scaling well below the core count)',
+    return dict(value=n / el, unit='blocks/s', cores=torch.get_num_threads(), threads_used=torch.get_num_threads(), kind='port',
+                host_logical_cores=os.cpu_count(), cpu_quota_cores=ops.usable_cores(),
+                note='cores = threads_used = oneDNN intra-op threads, calibrated on one block among the counts the container\'s CPU '
+                     'quota allows (batch-1 convs stop scaling well below the core count); host_logical_cores = what the box shows',
                 sample=f'{n} c3p 64^3 blocks, batch 1 (model_types.py:192-198 loop), oracle/torch_oracle.py: '
                        f'PyTorch-CPU oneDNN fp32 convs + C range coder, {el:.1f} s')
 
