@@ -302,9 +302,11 @@ def main():
         gc.collect(); gc.disable()
     barrier()
     dev_allocs0 = torch.cuda.memory_stats(device).get('num_device_alloc', 0)
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     n_blocks, n_bytes, n_pts = run(args.steps)
     barrier()
+    host_cores_busy = (time.process_time() - cpu0) / (time.perf_counter() - t0)       # CPU time of all threads of this rank / wall time
     dev_allocs = torch.cuda.memory_stats(device).get('num_device_alloc', 0) - dev_allocs0      # hipMalloc calls inside the timed region (each one stalls the queue)
     if os.environ.get('PCC_BENCH_STAMPS'):      # arrival spacing of the chunks (ms), for pipeline debugging
         print('device allocations inside the timed region:', dev_allocs, file=sys.stderr)
@@ -415,7 +417,9 @@ def main():
                                     'fixed threshold idx 128, encode+decode (BASELINE.json configs[1])') if args.workload == 'configs1' else
                                    ('deepest config (paper c6 = the c3p graph), batch=8 synthetic 128^3 occupancy grids per GPU, fp16 MFMA with fp16 '
                                     'mid-network storage, fixed threshold idx 128, encode+decode (BASELINE.json configs[4])'),
-                       'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'coder_threads_per_rank': coder_threads, 'sharding': f'blocks x{world}',
+                       'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'coder_threads_per_rank': coder_threads,
+                       'host_cores_busy_per_rank': round(host_cores_busy, 2), 'host_cpu_quota_cores': ops.usable_cores(),
+                       'device_allocations_in_timed_region': dev_allocs, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
                        'bytes_per_block': n_bytes / n_blocks, 'decoded_points_per_block': n_pts / n_blocks,
                        'conv_tflops_whole_step_algorithmic': value * FLOPS_PER_BLOCK / 1e12,
