@@ -129,6 +129,17 @@ def synthetic_blocks(n, device, seed0):
     return out
 
 
+def throttled_periods():
+    """Scheduler periods in which this container was paused for exceeding its CPU quota (cgroup v2 cpu.stat), or None."""
+    try:
+        for line in open('/sys/fs/cgroup/cpu.stat'):
+            if line.startswith('nr_throttled'):
+                return int(line.split()[1])
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(model, w, blocks_np, budget_s=12.0):
     """The oracle's PyTorch-CPU port of the reference's batch-1 per-block loop, on the host cores."""
     from oracle import oracle as O
@@ -309,9 +320,11 @@ def main():
     barrier()
     dev_allocs0 = torch.cuda.memory_stats(device).get('num_device_alloc', 0)
     cpu0 = time.process_time()
+    thr0 = throttled_periods()
     t0 = time.perf_counter()
     n_blocks, n_bytes, n_pts = run(args.steps)
     barrier()
+    thr1 = throttled_periods()
     host_cores_busy = (time.process_time() - cpu0) / (time.perf_counter() - t0)       # CPU time of all threads of this rank / wall time
     dev_allocs = torch.cuda.memory_stats(device).get('num_device_alloc', 0) - dev_allocs0      # hipMalloc calls inside the timed region (each one stalls the queue)
     if os.environ.get('PCC_BENCH_STAMPS'):      # arrival spacing of the chunks (ms), for pipeline debugging
@@ -368,17 +381,19 @@ def main():
         run(2, m2, ch2)
         ops.profile_select(ctx, L.PCC_NET_SYNTHESIS_PROGRESSIVE_V2, DOM_LAYER)
         torch.cuda.synchronize(device)
+        th2 = throttled_periods()
         s0 = time.perf_counter()
         nb2, nby2, npt2 = run(steps2, m2, ch2)
         torch.cuda.synchronize(device)
         el2 = time.perf_counter() - s0
+        th2 = None if th2 is None else throttled_periods() - th2
         k2 = ops.profile_read(ctx)
         ops.profile_select(ctx, -1, -1)
         avg2 = float(np.mean(k2)) if k2 else float('nan')
         bytes2 = 3.0 * batch2 * res2 ** 3 * 16 * 2
         secondary = {'metric': 'voxel_blocks_128cubed_per_sec_encode_decode_FP16_MODE', 'value': nb2 / el2, 'unit': '128^3 blocks/s',
                      'equivalent_64cubed_blocks_per_s': 8 * nb2 / el2, 'steps': steps2, 'warmup': 2, 'ms_per_step': 1e3 * el2 / steps2,
-                     'steady_ms_per_step': steady_ms_per_step(1),
+                     'steady_ms_per_step': steady_ms_per_step(1), 'cpu_quota_throttled_periods': th2,
                      'dtype': 'f16 operands and mid-network storage / f32 accumulate', 'data': 'synthetic',
                      'config': {'workload': 'BASELINE.json configs[4]: deepest config (paper c6 = the c3p graph), batch=8 synthetic 128^3 occupancy grids, '
                                             'fp16 MFMA with fp16 mid-network storage, fixed threshold idx 128, encode+decode',
@@ -425,7 +440,8 @@ def main():
                                     'mid-network storage, fixed threshold idx 128, encode+decode (BASELINE.json configs[4])'),
                        'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'coder_threads_per_rank': coder_threads,
                        'host_cores_busy_per_rank': round(host_cores_busy, 2), 'host_cpu_quota_cores': ops.usable_cores(),
-                       'device_allocations_in_timed_region': dev_allocs, 'sharding': f'blocks x{world}',
+                       'device_allocations_in_timed_region': dev_allocs,
+                       'cpu_quota_throttled_periods_in_timed_region': None if thr0 is None else thr1 - thr0, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
                        'bytes_per_block': n_bytes / n_blocks, 'decoded_points_per_block': n_pts / n_blocks,
                        'conv_tflops_whole_step_algorithmic': value * FLOPS_PER_BLOCK / 1e12,

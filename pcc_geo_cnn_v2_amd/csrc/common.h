@@ -64,6 +64,14 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
 uint32_t* pcc_threshold_mask_of(int32_t* scratch, int32_t B, int32_t D);
 int pcc_threshold_from_mask(pcc_ctx* ctx, int32_t B, int32_t D, int32_t H, int32_t W, float* xyz, int32_t* counts, int64_t cap,
                             int32_t* scratch, hipStream_t st);
+// fused element-wise steps of the codec graphs (elementwise.hip): quantiser + pack, scale fold + pack, unpack + dequantiser
+int pcc_quantize_pack(pcc_ctx* ctx, const float* v, const float* medians, int32_t* sym, float* deq, int32_t N, int64_t vox,
+                      int32_t C, int32_t mode, int32_t channels_first, void* dst, int32_t dst_bytes, int32_t* tile_max,
+                      void* stream);
+int pcc_index_pack(pcc_ctx* ctx, const float* sigma, const float* table, int32_t L, int32_t* idx, int32_t N, int64_t vox,
+                   int32_t C, int32_t channels_first, void* dst, int32_t dst_bytes, void* stream);
+int pcc_unpack_dequantize(pcc_ctx* ctx, const void* src, int32_t src_bytes, int32_t N, int64_t vox, int32_t C,
+                          int32_t channels_first, int32_t* sym, const float* medians, float* deq, void* stream);
 // Winograd F(2x2,3x3) (x,y) + direct z path for 16->16 and 32->32 k3 stride-1 layers (conv_wino.hip)
 bool pcc_wino_eligible(const pcc_conv_desc* d);
 int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* u_packed,

@@ -70,28 +70,116 @@ __device__ __forceinline__ T narrow(int32_t v) { return (T)v; }
 template <typename T, int N>
 struct alignas(sizeof(T) * N) PackVec { T v[N]; };
 
-template <typename T>
-__global__ void __launch_bounds__(kThreads) k_symbols_pack(const int32_t* __restrict__ src, T* __restrict__ dst, int vox, int C,
+// What the pack kernel packs: int32 values that exist already (SRC_INT), or values it produces itself on the way -- the
+// quantiser (SRC_QUANT: float -> symbol, also written as int32 + dequantised float in NDHWC) or the scale -> CDF-row fold
+// (SRC_INDEX) -- so that the encoder / decoder graphs need one launch where they had two.
+enum { SRC_INT = 0, SRC_QUANT = 1, SRC_INDEX = 2 };
+struct PackSrc {
+    const int32_t* isrc;      // SRC_INT
+    const float* fsrc;        // SRC_QUANT: values; SRC_INDEX: sigma
+    const float* med;         // SRC_QUANT: medians (C) or NULL
+    int32_t* sym;             // SRC_QUANT / SRC_INDEX: int32 NDHWC output
+    float* deq;               // SRC_QUANT: dequantised output (may be NULL)
+    const float* table;       // SRC_INDEX: scale table
+    int mode, L;
+};
+
+// idx = (L-1) - #{j < L-1 : sigma <= table[j]} (patch_gaussian_conditional.py:104-116).  For an ascending table -- what
+// the reference builds -- that count is a lower bound, found in log2(L) steps; any other table takes the literal count.
+__device__ __forceinline__ int scale_row(float sg, const float* tab, int L, bool ascending) {
+    if (!(sg >= tab[0])) sg = tab[0];
+    if (ascending) {
+        int lo = 0, n = L - 1;                 // first j in [0, L-1) with tab[j] >= sg
+        while (n > 0) {
+            const int half = n >> 1;
+            if (tab[lo + half] < sg) { lo += half + 1; n -= half + 1; } else n = half;
+        }
+        return lo;
+    }
+    int id = L - 1;
+    for (int j = 0; j < L - 1; ++j) id -= (sg <= tab[j]) ? 1 : 0;
+    return id;
+}
+
+template <int SRC>
+__device__ __forceinline__ int32_t produce(const PackSrc& ps, size_t gi, int c, const float* tab, bool ascending) {
+    if constexpr (SRC == SRC_INT) {
+        return ps.isrc[gi];
+    } else if constexpr (SRC == SRC_QUANT) {
+        const float m = ps.med ? ps.med[c] : 0.f;
+        const float q = ps.mode == PCC_ROUND_FLOOR_HALF ? floorf(ps.fsrc[gi] + (0.5f - m)) : rintf(ps.fsrc[gi] - m);   // as k_quantize
+        ps.sym[gi] = (int32_t)q;
+        if (ps.deq) ps.deq[gi] = q + m;
+        return (int32_t)q;
+    } else {
+        const int id = scale_row(ps.fsrc[gi], tab, ps.L, ascending);                                                   // == k_scale_index
+        ps.sym[gi] = id;
+        return id;
+    }
+}
+
+template <typename T, int SRC>
+__global__ void __launch_bounds__(kThreads) k_symbols_pack(PackSrc ps, T* __restrict__ dst, int vox, int C,
                                                             int vtiles, int ctiles, int channels_first,
                                                             int32_t* __restrict__ tile_max) {
     __shared__ int32_t tile[kPackT][kPackT + 1];
     __shared__ int32_t wmax[kThreads / 64];
+    __shared__ float tab[SRC == SRC_INDEX ? 256 : 1];
+    bool ascending = false;
+    if constexpr (SRC == SRC_INDEX) {
+        for (int j = threadIdx.x; j < ps.L; j += kThreads) tab[j] = ps.table[j];
+        __syncthreads();
+        int ok = 1;
+        for (int j = threadIdx.x; j + 1 < ps.L; j += kThreads) ok &= tab[j] <= tab[j + 1];
+        ascending = __syncthreads_and(ok) != 0;
+    }
     int t = blockIdx.x;
     const int ct = t % ctiles; t /= ctiles;
     const int vt = t % vtiles;
     const int n = t / vtiles;
     const int v0 = vt * kPackT, c0 = ct * kPackT;
     const int nv = min(kPackT, vox - v0), nc = min(kPackT, C - c0);
-    const int32_t* sb = src + ((size_t)n * vox + v0) * C + c0;
+    const size_t g0 = ((size_t)n * vox + v0) * C + c0;        // NDHWC index of the tile's first element
     int32_t m = 0;
     const bool full = nv == kPackT && nc == kPackT && (C & 3) == 0 && (vox & 3) == 0;     // whole, 16-byte aligned tile
     if (channels_first && full) {
         // four 16-byte loads per thread in flight, then LDS; four consecutive voxels per store on the way out
         int4 x[4];
+        if constexpr (SRC == SRC_INT) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = threadIdx.x + k * kThreads, v = i >> 4, q = i & 15;
-            x[k] = *reinterpret_cast<const int4*>(sb + (size_t)v * C + q * 4);
+            for (int k = 0; k < 4; ++k) {
+                const int i = threadIdx.x + k * kThreads, v = i >> 4, q = i & 15;
+                x[k] = *reinterpret_cast<const int4*>(ps.isrc + g0 + (size_t)v * C + q * 4);
+            }
+        } else {
+            float4 f[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = threadIdx.x + k * kThreads, v = i >> 4, q = i & 15;
+                f[k] = *reinterpret_cast<const float4*>(ps.fsrc + g0 + (size_t)v * C + q * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = threadIdx.x + k * kThreads, v = i >> 4, q = i & 15;
+                const size_t gi = g0 + (size_t)v * C + q * 4;
+                const float fv[4] = {f[k].x, f[k].y, f[k].z, f[k].w};
+                int32_t r[4];
+                if constexpr (SRC == SRC_QUANT) {
+                    float dq[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float md = ps.med ? ps.med[c0 + q * 4 + e] : 0.f;
+                        const float qq = ps.mode == PCC_ROUND_FLOOR_HALF ? floorf(fv[e] + (0.5f - md)) : rintf(fv[e] - md);
+                        r[e] = (int32_t)qq; dq[e] = qq + md;
+                    }
+                    if (ps.deq) *reinterpret_cast<float4*>(ps.deq + gi) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = scale_row(fv[e], tab, ps.L, ascending);
+                }
+                x[k] = make_int4(r[0], r[1], r[2], r[3]);
+                *reinterpret_cast<int4*>(ps.sym + gi) = x[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -99,37 +187,40 @@ __global__ void __launch_bounds__(kThreads) k_symbols_pack(const int32_t* __rest
             tile[q * 4 + 0][v] = x[k].x; tile[q * 4 + 1][v] = x[k].y; tile[q * 4 + 2][v] = x[k].z; tile[q * 4 + 3][v] = x[k].w;
             m = max(max(m, abs(x[k].x)), max(max(abs(x[k].y), abs(x[k].z)), abs(x[k].w)));
         }
-        __syncthreads();
-        T* db = dst + ((size_t)n * C + c0) * vox + v0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = threadIdx.x + k * kThreads, c = i >> 4, vq = i & 15;
-            PackVec<T, 4> o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o.v[e] = narrow<T>(tile[c][vq * 4 + e]);
-            *reinterpret_cast<PackVec<T, 4>*>(db + (size_t)c * vox + vq * 4) = o;
-        }
     } else if (channels_first) {
         for (int i = threadIdx.x; i < nv * kPackT; i += kThreads) {
             const int v = i / kPackT, c = i % kPackT;
             if (c < nc) {
-                const int32_t x = sb[(size_t)v * C + c];
+                const int32_t x = produce<SRC>(ps, g0 + (size_t)v * C + c, c0 + c, tab, ascending);
                 tile[c][v] = x;
                 m = max(m, abs(x));
             }
         }
+    }
+    if (channels_first) {
         __syncthreads();
         T* db = dst + ((size_t)n * C + c0) * vox + v0;
-        for (int i = threadIdx.x; i < nc * kPackT; i += kThreads) {
-            const int c = i / kPackT, v = i % kPackT;
-            if (v < nv) db[(size_t)c * vox + v] = narrow<T>(tile[c][v]);
+        if (nv == kPackT && nc == kPackT && (vox & 3) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = threadIdx.x + k * kThreads, c = i >> 4, vq = i & 15;
+                PackVec<T, 4> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.v[e] = narrow<T>(tile[c][vq * 4 + e]);
+                *reinterpret_cast<PackVec<T, 4>*>(db + (size_t)c * vox + vq * 4) = o;
+            }
+        } else {
+            for (int i = threadIdx.x; i < nc * kPackT; i += kThreads) {
+                const int c = i / kPackT, v = i % kPackT;
+                if (v < nv) db[(size_t)c * vox + v] = narrow<T>(tile[c][v]);
+            }
         }
     } else {
-        T* db = dst + ((size_t)n * vox + v0) * C + c0;
+        T* db = dst + g0;
         for (int i = threadIdx.x; i < nv * kPackT; i += kThreads) {
             const int v = i / kPackT, c = i % kPackT;
             if (c < nc) {
-                const int32_t x = sb[(size_t)v * C + c];
+                const int32_t x = produce<SRC>(ps, g0 + (size_t)v * C + c, c0 + c, tab, ascending);
                 db[(size_t)v * C + c] = narrow<T>(x);
                 m = max(m, abs(x));
             }
@@ -143,9 +234,11 @@ __global__ void __launch_bounds__(kThreads) k_symbols_pack(const int32_t* __rest
     }
 }
 
+// deq != NULL: the dequantiser rides along (deq = float(symbol) + medians[c], as k_dequantize)
 template <typename T>
 __global__ void __launch_bounds__(kThreads) k_symbols_unpack(const T* __restrict__ src, int32_t* __restrict__ dst, int vox, int C,
-                                                              int vtiles, int ctiles, int channels_first) {
+                                                              int vtiles, int ctiles, int channels_first,
+                                                              const float* __restrict__ med, float* __restrict__ deq) {
     __shared__ int32_t tile[kPackT][kPackT + 1];
     int t = blockIdx.x;
     const int ct = t % ctiles; t /= ctiles;
@@ -153,7 +246,8 @@ __global__ void __launch_bounds__(kThreads) k_symbols_unpack(const T* __restrict
     const int n = t / vtiles;
     const int v0 = vt * kPackT, c0 = ct * kPackT;
     const int nv = min(kPackT, vox - v0), nc = min(kPackT, C - c0);
-    int32_t* db = dst + ((size_t)n * vox + v0) * C + c0;
+    const size_t g0 = ((size_t)n * vox + v0) * C + c0;
+    int32_t* db = dst + g0;
     const bool full = nv == kPackT && nc == kPackT && (C & 3) == 0 && (vox & 3) == 0;
     if (channels_first && full) {
         const T* sb = src + ((size_t)n * C + c0) * vox + v0;
@@ -173,8 +267,13 @@ __global__ void __launch_bounds__(kThreads) k_symbols_unpack(const T* __restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = threadIdx.x + k * kThreads, v = i >> 4, q = i & 15;
-            *reinterpret_cast<int4*>(db + (size_t)v * C + q * 4) =
-                make_int4(tile[q * 4 + 0][v], tile[q * 4 + 1][v], tile[q * 4 + 2][v], tile[q * 4 + 3][v]);
+            const int4 sv = make_int4(tile[q * 4 + 0][v], tile[q * 4 + 1][v], tile[q * 4 + 2][v], tile[q * 4 + 3][v]);
+            *reinterpret_cast<int4*>(db + (size_t)v * C + q * 4) = sv;
+            if (deq) {
+                const float4 mv = med ? *reinterpret_cast<const float4*>(med + c0 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(deq + g0 + (size_t)v * C + q * 4) =
+                    make_float4((float)sv.x + mv.x, (float)sv.y + mv.y, (float)sv.z + mv.z, (float)sv.w + mv.w);
+            }
         }
     } else if (channels_first) {
         const T* sb = src + ((size_t)n * C + c0) * vox + v0;
@@ -185,13 +284,20 @@ __global__ void __launch_bounds__(kThreads) k_symbols_unpack(const T* __restrict
         __syncthreads();
         for (int i = threadIdx.x; i < nv * kPackT; i += kThreads) {
             const int v = i / kPackT, c = i % kPackT;
-            if (c < nc) db[(size_t)v * C + c] = tile[c][v];
+            if (c < nc) {
+                db[(size_t)v * C + c] = tile[c][v];
+                if (deq) deq[g0 + (size_t)v * C + c] = (float)tile[c][v] + (med ? med[c0 + c] : 0.f);
+            }
         }
     } else {
-        const T* sb = src + ((size_t)n * vox + v0) * C + c0;
+        const T* sb = src + g0;
         for (int i = threadIdx.x; i < nv * kPackT; i += kThreads) {
             const int v = i / kPackT, c = i % kPackT;
-            if (c < nc) db[(size_t)v * C + c] = (int32_t)sb[(size_t)v * C + c];
+            if (c < nc) {
+                const int32_t x = (int32_t)sb[(size_t)v * C + c];
+                db[(size_t)v * C + c] = x;
+                if (deq) deq[g0 + (size_t)v * C + c] = (float)x + (med ? med[c0 + c] : 0.f);
+            }
         }
     }
 }
@@ -454,28 +560,55 @@ PCC_API size_t pcc_symbols_tiles(int32_t N, int64_t vox, int32_t C) {
     return (size_t)N * (size_t)((vox + kPackT - 1) / kPackT) * (size_t)((C + kPackT - 1) / kPackT);
 }
 
-PCC_API int pcc_symbols_pack(pcc_ctx* ctx, const int32_t* src, int32_t N, int64_t vox, int32_t C, int32_t channels_first,
-                             void* dst, int32_t dst_bytes, int32_t* tile_max, void* stream) {
-    PCC_REQUIRE(ctx && src && dst, "pcc_symbols_pack: NULL argument");
-    PCC_REQUIRE(N > 0 && vox > 0 && vox < (1LL << 31) && C > 0, "pcc_symbols_pack: bad dimension");
-    PCC_REQUIRE(dst_bytes == 1 || dst_bytes == 2 || dst_bytes == 4, "pcc_symbols_pack: dst_bytes must be 1, 2 or 4");
+template <int SRC>
+static int launch_pack(pcc_ctx* ctx, const PackSrc& ps, int32_t N, int64_t vox, int32_t C, int32_t channels_first, void* dst,
+                       int32_t dst_bytes, int32_t* tile_max, void* stream, const char* who) {
+    PCC_REQUIRE(ctx && dst, "%s: NULL argument", who);
+    PCC_REQUIRE(N > 0 && vox > 0 && vox < (1LL << 31) && C > 0, "%s: bad dimension", who);
+    PCC_REQUIRE(dst_bytes == 1 || dst_bytes == 2 || dst_bytes == 4, "%s: dst_bytes must be 1, 2 or 4", who);
     PCC_CHECK_HIP(hipSetDevice(ctx->device));
     const int vt = (int)((vox + kPackT - 1) / kPackT), ct = (C + kPackT - 1) / kPackT;
     const size_t tiles = (size_t)N * vt * ct;
-    PCC_REQUIRE(tiles < (1ull << 31), "pcc_symbols_pack: too many tiles for one launch");
+    PCC_REQUIRE(tiles < (1ull << 31), "%s: too many tiles for one launch", who);
     hipStream_t st = (hipStream_t)stream;
     if (dst_bytes == 1)
-        hipLaunchKernelGGL(k_symbols_pack<uint8_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, src, (uint8_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
+        hipLaunchKernelGGL((k_symbols_pack<uint8_t, SRC>), dim3((unsigned)tiles), dim3(kThreads), 0, st, ps, (uint8_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
     else if (dst_bytes == 2)
-        hipLaunchKernelGGL(k_symbols_pack<int16_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, src, (int16_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
+        hipLaunchKernelGGL((k_symbols_pack<int16_t, SRC>), dim3((unsigned)tiles), dim3(kThreads), 0, st, ps, (int16_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
     else
-        hipLaunchKernelGGL(k_symbols_pack<int32_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, src, (int32_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
+        hipLaunchKernelGGL((k_symbols_pack<int32_t, SRC>), dim3((unsigned)tiles), dim3(kThreads), 0, st, ps, (int32_t*)dst, (int)vox, C, vt, ct, channels_first, tile_max);
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;
 }
 
-PCC_API int pcc_symbols_unpack(pcc_ctx* ctx, const void* src, int32_t src_bytes, int32_t N, int64_t vox, int32_t C,
-                               int32_t channels_first, int32_t* dst, void* stream) {
+PCC_API int pcc_symbols_pack(pcc_ctx* ctx, const int32_t* src, int32_t N, int64_t vox, int32_t C, int32_t channels_first,
+                             void* dst, int32_t dst_bytes, int32_t* tile_max, void* stream) {
+    PCC_REQUIRE(src, "pcc_symbols_pack: NULL argument");
+    PackSrc ps = {};
+    ps.isrc = src;
+    return launch_pack<SRC_INT>(ctx, ps, N, vox, C, channels_first, dst, dst_bytes, tile_max, stream, "pcc_symbols_pack");
+}
+
+// quantiser + pack / scale fold + pack / unpack + dequantiser in one launch each (the codec graphs, network.hip)
+int pcc_quantize_pack(pcc_ctx* ctx, const float* v, const float* medians, int32_t* sym, float* deq, int32_t N, int64_t vox,
+                      int32_t C, int32_t mode, int32_t channels_first, void* dst, int32_t dst_bytes, int32_t* tile_max,
+                      void* stream) {
+    PCC_REQUIRE(v && sym && (mode == PCC_ROUND_FLOOR_HALF || mode == PCC_ROUND_HALF_EVEN), "pcc_quantize_pack: bad argument");
+    PackSrc ps = {};
+    ps.fsrc = v; ps.med = medians; ps.sym = sym; ps.deq = deq; ps.mode = mode;
+    return launch_pack<SRC_QUANT>(ctx, ps, N, vox, C, channels_first, dst, dst_bytes, tile_max, stream, "pcc_quantize_pack");
+}
+
+int pcc_index_pack(pcc_ctx* ctx, const float* sigma, const float* table, int32_t L, int32_t* idx, int32_t N, int64_t vox,
+                   int32_t C, int32_t channels_first, void* dst, int32_t dst_bytes, void* stream) {
+    PCC_REQUIRE(sigma && table && idx && L >= 1 && L <= 256, "pcc_index_pack: bad argument");
+    PackSrc ps = {};
+    ps.fsrc = sigma; ps.table = table; ps.L = L; ps.sym = idx;
+    return launch_pack<SRC_INDEX>(ctx, ps, N, vox, C, channels_first, dst, dst_bytes, nullptr, stream, "pcc_index_pack");
+}
+
+static int launch_unpack(pcc_ctx* ctx, const void* src, int32_t src_bytes, int32_t N, int64_t vox, int32_t C,
+                         int32_t channels_first, int32_t* dst, const float* med, float* deq, void* stream) {
     PCC_REQUIRE(ctx && src && dst, "pcc_symbols_unpack: NULL argument");
     PCC_REQUIRE(N > 0 && vox > 0 && vox < (1LL << 31) && C > 0, "pcc_symbols_unpack: bad dimension");
     PCC_REQUIRE(src_bytes == 1 || src_bytes == 2 || src_bytes == 4, "pcc_symbols_unpack: src_bytes must be 1, 2 or 4");
@@ -485,13 +618,24 @@ PCC_API int pcc_symbols_unpack(pcc_ctx* ctx, const void* src, int32_t src_bytes,
     PCC_REQUIRE(tiles < (1ull << 31), "pcc_symbols_unpack: too many tiles for one launch");
     hipStream_t st = (hipStream_t)stream;
     if (src_bytes == 1)
-        hipLaunchKernelGGL(k_symbols_unpack<uint8_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const uint8_t*)src, dst, (int)vox, C, vt, ct, channels_first);
+        hipLaunchKernelGGL(k_symbols_unpack<uint8_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const uint8_t*)src, dst, (int)vox, C, vt, ct, channels_first, med, deq);
     else if (src_bytes == 2)
-        hipLaunchKernelGGL(k_symbols_unpack<int16_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const int16_t*)src, dst, (int)vox, C, vt, ct, channels_first);
+        hipLaunchKernelGGL(k_symbols_unpack<int16_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const int16_t*)src, dst, (int)vox, C, vt, ct, channels_first, med, deq);
     else
-        hipLaunchKernelGGL(k_symbols_unpack<int32_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const int32_t*)src, dst, (int)vox, C, vt, ct, channels_first);
+        hipLaunchKernelGGL(k_symbols_unpack<int32_t>, dim3((unsigned)tiles), dim3(kThreads), 0, st, (const int32_t*)src, dst, (int)vox, C, vt, ct, channels_first, med, deq);
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;
+}
+
+PCC_API int pcc_symbols_unpack(pcc_ctx* ctx, const void* src, int32_t src_bytes, int32_t N, int64_t vox, int32_t C,
+                               int32_t channels_first, int32_t* dst, void* stream) {
+    return launch_unpack(ctx, src, src_bytes, N, vox, C, channels_first, dst, nullptr, nullptr, stream);
+}
+
+int pcc_unpack_dequantize(pcc_ctx* ctx, const void* src, int32_t src_bytes, int32_t N, int64_t vox, int32_t C,
+                          int32_t channels_first, int32_t* sym, const float* medians, float* deq, void* stream) {
+    PCC_REQUIRE(deq, "pcc_unpack_dequantize: NULL argument");
+    return launch_unpack(ctx, src, src_bytes, N, vox, C, channels_first, sym, medians, deq, stream);
 }
 
 PCC_API int pcc_voxelize(pcc_ctx* ctx, const int32_t* pts, const int32_t* block_of, int64_t npts, int32_t B, int32_t D,

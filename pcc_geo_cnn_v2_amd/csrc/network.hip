@@ -434,43 +434,36 @@ PCC_API int pcc_codec_encode(pcc_ctx* ctx, const pcc_codec_desc* c, const float*
     const size_t ny = (size_t)N * (D / 8) * (H / 8) * (W / 8) * F;
     rc = pcc_network_forward(ctx, c->analysis, F, c->w_analysis, x, N, D, H, W, y, workspace, workspace_bytes, layer_flags, 0, stream);
     if (rc != PCC_OK) return rc;
+    // quantisers and the scale fold; with a sink each of them also packs its result for the host coder (stream order, narrow
+    // integers, tile maxima) in the same launch, so that the caller's side stream carries one copy and no kernel
+    rc = check_io(sink, "pcc_codec_encode");
+    if (rc != PCC_OK) return rc;
+    const int64_t vy = (int64_t)(D / 8) * (H / 8) * (W / 8), vz = (int64_t)(D / 16) * (H / 16) * (W / 16);
+    const int cf = sink ? sink->channels_first : 0;
+    auto quantize = [&](const float* v, const float* med, int32_t* sym, float* deq, int64_t vox, void* packed, int32_t* tmax) {
+        if (sink && packed) return pcc_quantize_pack(ctx, v, med, sym, deq, N, vox, F, c->round_mode, cf, packed, sink->sym_bytes, tmax, stream);
+        return pcc_quantize(ctx, v, med, sym, deq, (size_t)N * vox * F, F, c->round_mode, stream);
+    };
     if (c->version == 1) {
-        rc = pcc_quantize(ctx, y, c->medians, ysym, y_hat, ny, F, c->round_mode, stream);
+        rc = quantize(y, c->medians, ysym, y_hat, vy, sink ? sink->ysym : nullptr, sink ? sink->ysym_tile_max : nullptr);
         if (rc != PCC_OK) return rc;
     } else {
         PCC_REQUIRE(c->w_hyper_analysis && z && zsym && z_hat && sigma && idx, "pcc_codec_encode: version 2 needs the hyper tensors");
-        const size_t nz = (size_t)N * (D / 16) * (H / 16) * (W / 16) * F;
         rc = pcc_network_forward(ctx, PCC_NET_HYPER_ANALYSIS, F, c->w_hyper_analysis, y, N, D / 8, H / 8, W / 8, z, workspace,
                                  workspace_bytes, layer_flags, 0, stream);
         if (rc != PCC_OK) return rc;
-        rc = pcc_quantize(ctx, z, c->medians, zsym, z_hat, nz, F, c->round_mode, stream);
+        rc = quantize(z, c->medians, zsym, z_hat, vz, sink ? sink->zsym : nullptr, sink ? sink->zsym_tile_max : nullptr);
         if (rc != PCC_OK) return rc;
         rc = pcc_network_forward(ctx, PCC_NET_HYPER_SYNTHESIS, F, c->w_hyper_synthesis, z_hat, N, D / 16, H / 16, W / 16, sigma,
                                  workspace, workspace_bytes, layer_flags, 0, stream);
         if (rc != PCC_OK) return rc;
-        rc = pcc_scale_to_index(ctx, sigma, c->scale_table, c->scale_levels, idx, ny, stream);
+        if (sink && sink->idx)
+            rc = pcc_index_pack(ctx, sigma, c->scale_table, c->scale_levels, idx, N, vy, F, cf, sink->idx, sink->idx_bytes, stream);
+        else
+            rc = pcc_scale_to_index(ctx, sigma, c->scale_table, c->scale_levels, idx, ny, stream);
         if (rc != PCC_OK) return rc;
-        rc = pcc_quantize(ctx, y, nullptr, ysym, y_hat, ny, F, c->round_mode, stream);
+        rc = quantize(y, nullptr, ysym, y_hat, vy, sink ? sink->ysym : nullptr, sink ? sink->ysym_tile_max : nullptr);
         if (rc != PCC_OK) return rc;
-    }
-    // the symbols leave in the coder's stream order and integer width: packed here, in order, so that the caller's side stream
-    // carries one copy and no kernel
-    if (sink) {
-        rc = check_io(sink, "pcc_codec_encode");
-        if (rc != PCC_OK) return rc;
-        const int64_t vy = (int64_t)(D / 8) * (H / 8) * (W / 8), vz = (int64_t)(D / 16) * (H / 16) * (W / 16);
-        if (sink->ysym) {
-            rc = pcc_symbols_pack(ctx, ysym, N, vy, F, sink->channels_first, sink->ysym, sink->sym_bytes, sink->ysym_tile_max, stream);
-            if (rc != PCC_OK) return rc;
-        }
-        if (c->version == 2 && sink->zsym) {
-            rc = pcc_symbols_pack(ctx, zsym, N, vz, F, sink->channels_first, sink->zsym, sink->sym_bytes, sink->zsym_tile_max, stream);
-            if (rc != PCC_OK) return rc;
-        }
-        if (c->version == 2 && sink->idx) {
-            rc = pcc_symbols_pack(ctx, idx, N, vy, F, sink->channels_first, sink->idx, sink->idx_bytes, nullptr, stream);
-            if (rc != PCC_OK) return rc;
-        }
     }
     // everything the range coder needs is final here: the caller's copy stream / host coder can start while the synthesis
     // transform (most of the work) is still being enqueued and executed
@@ -500,18 +493,18 @@ PCC_API int pcc_codec_decode_hyper(pcc_ctx* ctx, const pcc_codec_desc* c, int32_
     const size_t nz = (size_t)N * (D / 16) * (H / 16) * (W / 16) * F, ny = (size_t)N * (D / 8) * (H / 8) * (W / 8) * F;
     rc = check_io(io, "pcc_codec_decode_hyper");
     if (rc != PCC_OK) return rc;
-    if (io && io->zsym) {      // stream-order symbols as the host->device copy delivered them -> NDHWC int32
-        rc = pcc_symbols_unpack(ctx, io->zsym, io->sym_bytes, N, (int64_t)(nz / F / N), F, io->channels_first, zsym, stream);
-        if (rc != PCC_OK) return rc;
-    }
-    rc = pcc_dequantize(ctx, zsym, c->medians, z_hat, nz, F, stream);
+    if (io && io->zsym)        // stream-order symbols as the host->device copy delivered them -> NDHWC int32 + z_hat, one launch
+        rc = pcc_unpack_dequantize(ctx, io->zsym, io->sym_bytes, N, (int64_t)(nz / F / N), F, io->channels_first, zsym, c->medians, z_hat, stream);
+    else
+        rc = pcc_dequantize(ctx, zsym, c->medians, z_hat, nz, F, stream);
     if (rc != PCC_OK) return rc;
     rc = pcc_network_forward(ctx, PCC_NET_HYPER_SYNTHESIS, F, c->w_hyper_synthesis, z_hat, N, D / 16, H / 16, W / 16, sigma,
                              workspace, workspace_bytes, layer_flags, 0, stream);
     if (rc != PCC_OK) return rc;
-    rc = pcc_scale_to_index(ctx, sigma, c->scale_table, c->scale_levels, idx, ny, stream);
-    if (rc != PCC_OK || !io || !io->idx) return rc;
-    return pcc_symbols_pack(ctx, idx, N, (int64_t)(ny / F / N), F, io->channels_first, io->idx, io->idx_bytes, nullptr, stream);
+    if (io && io->idx)
+        return pcc_index_pack(ctx, sigma, c->scale_table, c->scale_levels, idx, N, (int64_t)(ny / F / N), F, io->channels_first, io->idx,
+                              io->idx_bytes, stream);
+    return pcc_scale_to_index(ctx, sigma, c->scale_table, c->scale_levels, idx, ny, stream);
 }
 
 // Decoder, main phase (model_types.py:305-307 V1, :407-408 V2): y symbols -> y_hat -> x_hat, then (optionally, thr != NULL)
@@ -528,11 +521,11 @@ PCC_API int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, int32_t
     const size_t ny = (size_t)N * (D / 8) * (H / 8) * (W / 8) * F;
     rc = check_io(io, "pcc_codec_decode_main");
     if (rc != PCC_OK) return rc;
-    if (io && io->ysym) {
-        rc = pcc_symbols_unpack(ctx, io->ysym, io->sym_bytes, N, (int64_t)(ny / F / N), F, io->channels_first, ysym, stream);
-        if (rc != PCC_OK) return rc;
-    }
-    rc = pcc_dequantize(ctx, ysym, c->version == 1 ? c->medians : nullptr, y_hat, ny, F, stream);
+    const float* ymed = c->version == 1 ? c->medians : nullptr;
+    if (io && io->ysym)
+        rc = pcc_unpack_dequantize(ctx, io->ysym, io->sym_bytes, N, (int64_t)(ny / F / N), F, io->channels_first, ysym, ymed, y_hat, stream);
+    else
+        rc = pcc_dequantize(ctx, ysym, ymed, y_hat, ny, F, stream);
     if (rc != PCC_OK) return rc;
     PCC_REQUIRE(!thr || (xyz && counts && scratch), "pcc_codec_decode_main: thr given but xyz / counts / scratch is NULL");
     static const bool no_fuse = getenv("PCC_NO_THR_FUSE") != nullptr;

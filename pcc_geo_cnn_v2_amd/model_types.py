@@ -91,6 +91,9 @@ def select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics, points, r
             for _, m, met in rank_candidates(opt_metrics, cand_metrics, opt_groups)]
 
 
+_SIDE_STREAMS = {}
+
+
 def _usable_cores():
     """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container that sees 256 cores may
     be throttled to 16 CPUs' worth of time per period -- running more threads than that gets the whole process paused)."""
@@ -197,9 +200,11 @@ class CompressionModel:
         different streams: '_copy_stream' (encoder symbols and decoded points to the host: each waits for an event of the main
         stream), '_up_stream' (decoder symbols to the device: no GPU-side dependency, they run as soon as the host has decoded
         them), '_idx_stream' (the decoder's CDF-row indexes to the host)."""
-        if not hasattr(self, which):
-            setattr(self, which, torch.cuda.Stream(ctx.device))
-        return getattr(self, which)
+        # one set per device for the whole process (streams are a runtime resource: every model on the device shares them)
+        key = (ctx.device.index, which)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(ctx.device)
+        return _SIDE_STREAMS[key]
 
     def _staging(self, ctx, slot, B, y_dhw, z_dhw=None):
         """Per pipeline slot: the device + pinned staging buffers of one encode (ops.SymbolStaging), cached."""
@@ -363,12 +368,11 @@ class CompressionModel:
             parts = [xyz[b, :int(cnt[b])] for b in range(len(cnt))]
             flat = torch.cat(parts).cpu().numpy() if len(parts) else np.zeros((0, 3), np.float32)
         else:
-            if not hasattr(self, '_copy_stream'):
-                self._copy_stream = torch.cuda.Stream(ctx.device)
-            with torch.cuda.stream(self._copy_stream):
-                self._copy_stream.wait_event(ready)
-                xyz.record_stream(self._copy_stream)
-                counts.record_stream(self._copy_stream)
+            side = self._side_stream(ctx)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                xyz.record_stream(side)
+                counts.record_stream(side)
                 cnt = counts.cpu().numpy()
                 parts = [xyz[b, :int(cnt[b])] for b in range(len(cnt))]
                 flat = torch.cat(parts).cpu().numpy() if len(parts) else np.zeros((0, 3), np.float32)
