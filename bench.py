@@ -42,6 +42,19 @@ PEAK_FP32_MFMA = 157.3       # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16
 GAIN_ANALYSIS, GAIN_SYNTHESIS, FINAL_BIAS, EB_INIT_SCALE = 1.35, 1.8, 0.0, 0.2
 
 
+def wino_exec_factor(ch, d, batch, num_cu=256):
+    """Executed / direct-convolution MFMA flops of a k3 stride-1 layer on csrc/conv_wino.hip: 16 instead of 36 multiplies per 2x2
+    outputs and z tap, times the input planes a slab marches.  z-split as in pcc_conv_wino (the split that gives every CU a
+    workgroup).  16-channel kernel: a slab runs (2/3 if it starts at z = 0 else 1) + zlen - (1 if it ends at z = D) plane-equivalents
+    of MFMA rows (padding planes are skipped, the head planes run only the rows that feed this slab); the multi-group kernels:
+    zlen + 1 + 1/3 per slab."""
+    zs, base = 1, batch * (d // 16) ** 2 * (ch // 16)
+    while base * zs < num_cu and d % (zs * 2) == 0 and d // (zs * 2) >= (4 if ch >= 32 else 8):
+        zs *= 2
+    planes = d + zs - 4.0 / 3.0 if ch == 16 else d + zs * 4.0 / 3.0
+    return 16.0 / 36.0 * planes / d
+
+
 def c3p_step_flops(res, batch, num_cu=256, winograd=True):
     """(algorithmic, executed) fp32 MFMA flops of ONE block through compress graph + decompress graph of c3p (the unit of
     SURVEY.md 8d): algorithmic = direct convolution, 2 * MACs as the reference executes them; executed = what the kernels
@@ -52,11 +65,7 @@ def c3p_step_flops(res, batch, num_cu=256, winograd=True):
     def wino_factor(ch, d):
         if not winograd or d % 16:
             return 1.0
-        zs, base = 1, batch * (d // 16) ** 2 * (ch // 16)
-        while base * zs < num_cu and d % (zs * 2) == 0 and d // (zs * 2) >= (4 if ch >= 32 else 8):
-            zs *= 2
-        zlen = d // zs
-        return 16.0 / 36.0 * (zlen + 1 + 1.0 / 3.0) / zlen      # + a full tail plane + the dz-0 rows of the head plane
+        return wino_exec_factor(ch, d, batch, num_cu)
     alg = ex = 0.0
 
     def conv(cin, cout, k, d_out_or_in, wino=False):       # MACs counted on the grid the taps are applied on
@@ -410,18 +419,18 @@ def main():
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
         winograd = os.environ.get('PCC_NO_WINOGRAD') is None
         if winograd:
-            # conv_wino.hip: F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap), RES+2 input planes per RES outputs (the first one runs its dz = 0 rows only)
-            exec_flops = flops_launch * 16.0 / 36.0 * (RES + 1 + 1.0 / 3.0) / RES
+            # conv_wino.hip: F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap); padding planes skipped
+            exec_flops = flops_launch * wino_exec_factor(16, RES, args.chunk, ctx.num_cu)
             dom_kernel = 'conv16_wino_kernel<relu> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the decoder; layer 7 runs the same kernel: 4 launches per step)'
-            dom_note = ('achieved/frac = fp32 MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3) in x-y + direct z: 16/36 * 65.33/64 of '
-                        'the direct-convolution flops) / HIP-event launch time / dense fp32 MFMA peak; algorithmic_* restate it in the '
+            dom_note = ('achieved/frac = fp32 MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3) in x-y + direct z: 16/36 * 63.67/64 of '
+                        'the direct-convolution flops for a whole-volume slab) / HIP-event launch time / dense fp32 MFMA peak; algorithmic_* restate it in the '
                         'direct-convolution flops of SURVEY.md 8d (what a direct kernel would have to sustain for the same time)')
         else:
             exec_flops = flops_launch
             dom_kernel = 'conv16_pers_kernel<2,4,2,20,2> (Conv3DTranspose 16->16 k3 s1 @64^3, 4 launches per step)'
             dom_note = 'direct implicit-GEMM kernel (PCC_NO_WINOGRAD=1): executed == algorithmic flops'
         achieved_exec = exec_flops / (avg_ms * 1e-3) / 1e12
-        alg_step, exec_step = c3p_step_flops(RES, args.chunk, winograd=winograd)
+        alg_step, exec_step = c3p_step_flops(RES, args.chunk, num_cu=ctx.num_cu, winograd=winograd)
         assert abs(alg_step / FLOPS_PER_BLOCK - 1) < 2e-3, (alg_step, FLOPS_PER_BLOCK)       # the layer walk reproduces SURVEY.md 8d
         alg_bytes16 = 3.0 * args.chunk * RES ** 3 * 16 * 2            # fp16 mode: in + residual + out of the timed layer, fp16
         traffic, traffic_src = None, None

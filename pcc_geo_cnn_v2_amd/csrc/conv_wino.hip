@@ -128,6 +128,8 @@ __device__ __forceinline__ void transform_y_row(f32x4 (&V)[16], const f32x4 (&P)
 
 // PRE: this launch handles a later cin group of a multi-group layer launched group by group (clip layers; PCC_WINO_PER_GROUP):
 // the partial sums of the earlier groups are read back from `out` (same lane, same address as its own earlier store).
+enum { M_ALL = 0, M_S0 = 1, M_S1 = 2, M_S1O = 3, M_FIN = 4 };
+
 template <bool RELU, bool CLIP, bool PRE>
 __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -213,9 +215,14 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     const f32x4 bias_l = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + 16 * cog + g * 4) : zero4;
     const f32x4 bias4 = bias_l;
 
-    // ---- prologue: input planes s = 0, 1 (z = zb-1, zb) -> ring slots 0, 1
-    stage_plane(0, zb - 1);
-    stage_plane(PLANE_BYTES, zb);
+    // Planes outside the volume are zero (SAME padding): a slab that starts at z = 0 skips step 0 (its plane z = -1 would only
+    // deposit the bias) and a slab that ends at z = D runs its last step without matrix work (plane z = D adds nothing; the
+    // step only reduces and stores output plane D - 1).  Both conditions are wave-uniform and decided OUTSIDE the MFMA stream.
+    const bool first_zero = zb == 0, last_zero = zb + a.zlen == a.D;
+    const int s0 = first_zero ? 1 : 0;                                   // first step that runs
+    // ---- prologue: input planes s0, s0 + 1 -> their ring slots (plane s lives in slot s mod 3)
+    stage_plane((unsigned)s0 * PLANE_BYTES, zb - 1 + s0);
+    stage_plane((unsigned)(s0 + 1) * PLANE_BYTES, zb + s0);
     __syncthreads();
 
     f32x4 Vc[16];               // B^T d B of the current input plane (B operand of the MFMAs)
@@ -225,25 +232,32 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
     f32x4 S[2][2];              // A^T-reduced 2x2 outputs of the finished plane
     f32x4 resv[4], prev[4], ost[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i]);
+    for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i] + (unsigned)s0 * PLANE_BYTES);
     transform_x_rows(Vn, 0, 4);
     transform_y_row(Vc, Vn, 0);
     transform_y_row(Vc, Vn, 1);
     transform_y_row(Vc, Vn, 2);          // row 3 follows in slot 0 of the first step
+    // the first step that runs starts at its first ACTIVE row: (dz 0, py 0) = slot 8 of step 0, (dz 1, py 0) = slot 4 of step 1; both use buffer 0
 #pragma unroll
-    for (int px = 0; px < 4; ++px) Ub[0][px] = ldsr(ua + (unsigned)(px * 1024));   // first step: dz = 0 rows only; its first row (dz 0, py 0) is slot 8 -> buffer 0
+    for (int px = 0; px < 4; ++px) Ub[0][px] = ldsr(ua + (unsigned)((s0 * 16 + px) * 1024));
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }   // (planes finishing at s < 2 are never stored)
 
-    unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;     // plane zo of step s = 0
-    unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
+    unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2 + s0) * HWR;     // plane zo of step s0
+    unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2 + s0) * HWO;
+    in_pl += (unsigned long long)s0 * HWI;                                                                          // plane s0 + 2
     // one input plane: s = step index (input plane z = zb-1+s), PH = s mod 3
-    // DZ0: the slab's first input plane (zb - 1) only feeds output plane zb, through its dz = 0 rows -- 4 of the 12 MFMA rows
-    // (66 -> 65.33 plane-equivalents per 64-plane slab, 18 -> 17.33 per 16-plane slab); see conv16_wino_cin_kernel for why the last
-    // plane stays a full one
-    auto step = [&](auto ph_tag, int s, auto dz0_tag) __attribute__((always_inline)) {
+    // MODE: which of the 12 MFMA rows (dz = 2, 1, 0 x 4 point rows) a step runs.
+    //   M_ALL  every interior step
+    //   M_S0   step 0 (plane zb - 1 of a slab inside the volume): only its dz = 0 rows feed an output plane of this slab
+    //   M_S1   step 1 behind M_S0: its dz = 2 rows would finish output plane zb - 1, which belongs to the slab below
+    //   M_S1O  step 1 of a slab that starts at z = 0 (step 0 skipped): as M_S1, and its dz = 1 rows OPEN their accumulators
+    //   M_FIN  last step of a slab that ends at z = D: no matrix work, only the reduction + store of output plane D - 1
+    // (66 -> 65 plane-equivalents per 64-plane slab inside the volume, 66 -> 64.8 for a whole-volume slab)
+    auto step = [&](auto ph_tag, int s, auto mode_tag) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
-        constexpr bool DZ0 = decltype(dz0_tag)::value;
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool FIN = MODE == M_FIN;
         constexpr unsigned slotN = (unsigned)((PH + 1) % 3) * PLANE_BYTES;   // plane s+1 (read)
         constexpr unsigned slotW = (unsigned)((PH + 2) % 3) * PLANE_BYTES;   // plane s+2 (written)
         constexpr int AF = PH;                                               // acc slot of the plane finished by dz = 2
@@ -256,20 +270,22 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
         for (int j = 0; j < 12; ++j) {
             const int dz = 2 - (j >> 2), py = j & 3;
             const int as = (PH + 2 - dz) % 3;
-            // (1) U fragments of the next row (wraps to the first row of the next step)
-            if (!DZ0 || dz == 0) {
-                const int jn = (j + 1) % 12, dzn = 2 - (jn >> 2), pyn = jn & 3;
+            const bool active = MODE == M_ALL || (MODE == M_S0 && dz == 0) || ((MODE == M_S1 || MODE == M_S1O) && dz <= 1);
+            // (1) U fragments of the next row (wraps to the first active row of the next step: step 1 starts at its dz = 1 rows)
+            if (active) {
+                const int jn = (j == 11 && MODE == M_S0) ? 4 : (j + 1) % 12, dzn = 2 - (jn >> 2), pyn = jn & 3;
 #pragma unroll
                 for (int px = 0; px < 4; ++px) Ub[(j + 1) & 1][px] = ldsr(ua + (unsigned)(((dzn * 4 + pyn) * 4 + px) * 1024));
             }
             // (2) the 16 MFMAs of this row: 4 independent accumulators, k-chained; dz = 0 opens a new output plane
 #pragma unroll
-            for (int kk = 0; kk < (!DZ0 || dz == 0 ? 4 : 0); ++kk)
+            for (int kk = 0; kk < (active ? 4 : 0); ++kk)
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {
                     // a new output plane starts from 0, except point (1,1) which enters all four outputs with weight +1
                     // and therefore carries the bias for free
-                    const f32x4 c = (dz == 0 && kk == 0) ? ((py == 1 && px == 1) ? bias4 : zero4) : acc[as][py * 4 + px];
+                    const bool opens = dz == 0 || (MODE == M_S1O && dz == 1);
+                    const f32x4 c = (opens && kk == 0) ? ((py == 1 && px == 1) ? bias4 : zero4) : acc[as][py * 4 + px];
                     acc[as][py * 4 + px] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ub[j & 1][px][kk], Vc[py * 4 + px][kk], c, 0, 0, 0);
                 }
             // An fp32 MFMA and a VALU op of the same wave share the SIMD's FMA lanes (tools/ubench/mfma_valu.hip): every
@@ -278,7 +294,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
             __builtin_amdgcn_sched_barrier(0);
             // (3) everything else, spread over the slots.  Vc row r is last read by the MFMAs of slot 8+r, so the rows of
             //     the next plane are written in slots 9, 10, 11 and (row 3) slot 0 of the next step: no register copies.
-            if (j == 0) transform_y_row(Vc, Vn, 3);
+            if (FIN) {
+            } else if (j == 0) transform_y_row(Vc, Vn, 3);
             else if (j == 1) {
                 const bool ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
                 const __amdgpu_buffer_rsrc_t rp = make_rsrc((const void*)(ok ? in_pl : (unsigned long long)in_n), ok ? HWI : 0u);
@@ -290,7 +307,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
                 for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i] + slotN);
             } else if (j == 2) transform_x_rows(Vn, 0, 2);
             else if (j == 3) transform_x_rows(Vn, 2, 4);
-            else if (j == 4 || j == 5) {
+            if (j == 4 || j == 5) {
                 // residual (and partial sums of the previous cin groups, accumulated in place in `out`: same lane, same
                 // address) of the two voxels of output row oy = j - 4.  (Requesting them in slot 0 instead was measured: no
                 // change for the one-group layers, 8 % more cycles for the two-group ones.)
@@ -337,7 +354,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 #pragma unroll
                 for (int q = 2 * (j - 9); q < 2 * (j - 9) + 2; ++q) asm volatile("" ::"v"(ost[q]));
             }
-            if (j == 9) transform_y_row(Vc, Vn, 0);
+            if (FIN) {
+            } else if (j == 9) transform_y_row(Vc, Vn, 0);
             else if (j == 10) transform_y_row(Vc, Vn, 1);
             else if (j == 11) transform_y_row(Vc, Vn, 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -345,17 +363,36 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
         // The LDS-direct loads of plane s+2 (slot 1) must have landed before the barrier publishes them to the other
         // waves; the compiler only orders them against this wave's own LDS reads.  vmcnt counts in issue order: the 4
         // residual (+4 partial-sum) loads of slots 4 / 5 and the 4 stores of slots 8 / 9 were issued later and may stay in flight.
-        __builtin_amdgcn_s_waitcnt(PRE ? 0x0F7C : 0x0F78);      // vmcnt(12 / 8) expcnt(7) lgkmcnt(15)
-        __syncthreads();     // plane s+2 is published; nobody still reads plane s+1
+        if (!FIN) {
+            __builtin_amdgcn_s_waitcnt(PRE ? 0x0F7C : 0x0F78);      // vmcnt(12 / 8) expcnt(7) lgkmcnt(15)
+            __syncthreads();     // plane s+2 is published; nobody still reads plane s+1
+        }
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    using MAll = std::integral_constant<int, M_ALL>;
+    using MFin = std::integral_constant<int, M_FIN>;
 
-    step(std::integral_constant<int, 0>{}, 0, std::true_type{});
-    for (int s = 1; s < nsteps; s += 3) {
-        step(std::integral_constant<int, 1>{}, s, std::false_type{});
-        if (s + 1 < nsteps) step(std::integral_constant<int, 2>{}, s + 1, std::false_type{});
-        if (s + 2 < nsteps) step(std::integral_constant<int, 0>{}, s + 2, std::false_type{});
+    if (first_zero) step(P1{}, 1, std::integral_constant<int, M_S1O>{});
+    else {
+        step(P0{}, 0, std::integral_constant<int, M_S0>{});
+        step(P1{}, 1, std::integral_constant<int, M_S1>{});
+    }
+    const int nloop = nsteps - (last_zero ? 1 : 0);
+    for (int s = 2; s < nloop; s += 3) {
+        step(P2{}, s, MAll{});
+        if (s + 1 < nloop) step(P0{}, s + 1, MAll{});
+        if (s + 2 < nloop) step(P1{}, s + 2, MAll{});
+    }
+    if (last_zero) {
+        const int sl = nsteps - 1, ph = sl % 3;
+        if (ph == 0) step(P0{}, sl, MFin{});
+        else if (ph == 1) step(P1{}, sl, MFin{});
+        else step(P2{}, sl, MFin{});
     }
 }
+
 
 
 // ---------------------------------------------------------------------------------------------------------------------
