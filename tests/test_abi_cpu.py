@@ -153,3 +153,32 @@ def test_pmf_to_quantized_cdf_matches_oracle(oracle):
             b = oracle.pmf_to_quantized_cdf(p)
             assert a[0] == 0 and a[-1] == 1 << 16 and np.all(np.diff(a) >= 1)
             assert np.array_equal(a, b)
+
+
+def test_ctypes_structs_match_the_header_as_compiled_by_a_c_compiler(tmp_path):
+    """include/pcc_geo.h is a C header: a C compiler must accept it, and the sizes / field offsets it gives the ABI structs must be
+    the ones the ctypes mirror (pcc_geo_cnn_v2_amd/_lib.py) uses -- a silent mismatch would shift every pointer behind it."""
+    import shutil
+    import subprocess
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc is None:
+        pytest.skip('no C compiler')
+    structs = {'pcc_conv_desc': L.ConvDesc, 'pcc_cdf_table': L.CdfTable, 'pcc_codec_desc': L.CodecDesc, 'pcc_symbol_io': L.SymbolSink}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "pcc_geo.h")}"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({name}, {field}));')
+        lines.append('  printf("\\n");')
+    lines += ['  printf("abi %d\\n", PCC_ABI_VERSION);', '  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run([cc, '-std=c99', '-Wall', '-Werror', '-o', str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for line in out[:-1]:
+        name, size, *offs = line.split()
+        cls = structs[name]
+        assert int(size) == C.sizeof(cls), f'{name}: header {size} bytes, ctypes {C.sizeof(cls)}'
+        assert [int(o) for o in offs] == [getattr(cls, f).offset for f, _ in cls._fields_], f'{name}: field offsets differ'
+    assert out[-1] == f'abi {L.ABI_VERSION}'
