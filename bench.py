@@ -232,8 +232,8 @@ def dry_run(args, dist, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200, help='timed steps (default 200: about one second, so that pipeline fill and drain -- two chunks -- weigh 1 %%)')
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[4] (128^3, batch 8, fp16) measurement that the default run appends')
     ap.add_argument('--chunk', type=int, default=CHUNK)
