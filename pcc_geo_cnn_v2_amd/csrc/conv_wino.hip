@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_kernel(WinoArgs a, int nwg)
 // LDS (162816 B): ring of 3 tiles (18 x 18 x 16 ch; a tile is dead once its patches are in registers, so the ring is
 // indexed by m, not by (s, c)) + two U buffers of 48 KB.  G = 2: both cin groups' U stay resident (the second one streams in
 // during micro-step 0).  G = 4: U[c(m+1)] streams global(L2) -> LDS into the idle buffer during micro-step m, 12 pieces of
-// 1 KB per wave spread over slots 0..7 (48 KB per ~7k cycles and CU = 7 B/cycle, an eighth of the L2 rate).
+// 1 KB per wave in slots 0, 2..4 (48 KB per ~7k cycles and CU = 7 B/cycle, an eighth of the L2 rate).
 // The tile ring phase (m mod 3) is independent of the accumulator phase (s mod 3, compile time): the 16 patch addresses
 // advance by a wave-uniform delta per micro-step (16 v_add_u32) instead of being immediates.
 //
@@ -607,10 +607,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
                 for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i]);
             } else if (j == 2) transform_x_rows(Vn, 0, 2);
             else if (j == 3) transform_x_rows(Vn, 2, 4);
-            if (STREAM) {        // U[cn] -> the idle buffer: pieces 0..11 of this wave in slots 0, 2..7
-                if (j == 0) { stage_u(ub_next, cn, 0); stage_u(ub_next, cn, 1); }
-                else if (j >= 2 && j <= 5) { stage_u(ub_next, cn, 2 * j - 2); stage_u(ub_next, cn, 2 * j - 1); }
-                else if (j == 6 || j == 7) stage_u(ub_next, cn, j + 4);
+            if (STREAM) {        // U[cn] -> the idle buffer: pieces 0..11 of this wave in slots 0, 2..4
+                // (all 12 pieces are on their way by slot 4: the last ones then have 8 slots to land before the closing barrier waits for them)
+                if (j == 0) { stage_u(ub_next, cn, 0); stage_u(ub_next, cn, 1); stage_u(ub_next, cn, 2); }
+                else if (j >= 2 && j <= 4) { stage_u(ub_next, cn, 3 * j - 3); stage_u(ub_next, cn, 3 * j - 2); stage_u(ub_next, cn, 3 * j - 1); }
             }
             if (fin) {
                 if (j == 4 || j == 5) {
