@@ -248,3 +248,26 @@ def test_host_python_is_not_a_transcription_of_the_reference():
         for name in WATCHED & set(mine) & set(ref):
             r = difflib.SequenceMatcher(None, '\n'.join(mine[name]), '\n'.join(ref[name]), autojunk=False).ratio()
             assert r < 0.6, (name, r)
+
+
+def test_usable_cores_respects_affinity_and_quota(monkeypatch, tmp_path):
+    """Host thread counts follow what the container may really use: the affinity mask capped by the cgroup CPU quota."""
+    import builtins
+    import os
+    from pcc_geo_cnn_v2_amd import ops
+    n = ops.usable_cores()
+    assert 1 <= n <= (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count())
+    real_open = builtins.open
+
+    def fake(quota_line):
+        def _open(path, *a, **k):
+            if path == '/sys/fs/cgroup/cpu.max':
+                f = tmp_path / 'cpu.max'
+                f.write_text(quota_line)
+                return real_open(f, *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+    monkeypatch.setattr(builtins, 'open', fake('200000 100000\n'))
+    assert ops.usable_cores() == min(2, len(os.sched_getaffinity(0)))
+    monkeypatch.setattr(builtins, 'open', fake('max 100000\n'))
+    assert ops.usable_cores() == len(os.sched_getaffinity(0))
