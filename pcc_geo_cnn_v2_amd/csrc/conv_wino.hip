@@ -535,18 +535,21 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     // one micro-step.  PH = s mod 3 (accumulator rotation), FIRST / FIN = first / last cin group of the plane: all compile
     // time -- wave-uniform run-time branches around the slot pieces were measured at ~1000 cycles per micro-step (12 % of it:
     // every taken branch restarts the instruction fetch), more than the epilogue they skip.
-    // DZ0: the slab's first input plane (zb - 1) only feeds output plane zb, through its dz = 0 rows: that plane runs 4 of the 12
-    // MFMA rows (the rest of the step -- staging, input transform -- is unchanged): 10 -> 9.33 plane-equivalents per 8-plane slab
-    // (64 -> 64 @16^3), 34 -> 33.33 (32 -> 32 @32^3).  The mirror image for the last plane (dz = 2 rows only) was built too: as
-    // compile-time bodies its extra control flow around 192 live accumulator registers made the allocator spill (90 - 780
+    // The two head planes of a slab run only the MFMA rows that feed ITS output planes (ROWS below): plane 0 (zb - 1) its dz = 0 rows,
+    // plane 1 its dz = 1 and dz = 0 rows (the rest of the step -- staging, input transform -- is unchanged): 10 -> 9 plane-equivalents
+    // per 8-plane slab (64 -> 64 @16^3), 34 -> 33 (32 -> 32 @32^3).  The mirror image for the last plane (dz = 2 rows only) was built
+    // too: as compile-time bodies its extra control flow around 192 live accumulator registers made the allocator spill (90 - 780
     // registers, whatever the loop shape), as a run-time row mask the 12 scalar branches per micro-step cost the 32-channel layer
     // more (+7 % wave cycles) than the plane saves.
-    auto step = [&](auto ph_tag, auto first_tag, auto fin_tag, auto dz0_tag) __attribute__((always_inline)) {
+    auto step = [&](auto ph_tag, auto first_tag, auto fin_tag, auto rows_tag) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr int AF = PH;
         constexpr bool first = decltype(first_tag)::value, fin = decltype(fin_tag)::value;
-        constexpr bool DZ0 = decltype(dz0_tag)::value;
-        constexpr int J_FIRST_NEXT = (DZ0 && !fin) ? 8 : 0;      // first active row of the NEXT micro-step (the plane after the dz-0-only plane is a full one)
+        // ROWS: 0 = all 12 MFMA rows; 1 = plane 0 of the slab (zb - 1): dz = 0 rows only; 2 = plane 1: dz = 1 and dz = 0 rows (its
+        // dz = 2 rows would finish output plane zb - 1, which belongs to the slab below and is never stored)
+        constexpr int ROWS = decltype(rows_tag)::value;
+        constexpr int J_OWN = ROWS == 1 ? 8 : ROWS == 2 ? 4 : 0;                 // first active row of this plane's micro-steps
+        constexpr int J_FIRST_NEXT = !fin ? J_OWN : ROWS == 1 ? 4 : 0;           // ... of the NEXT micro-step (plane 0 -> plane 1 -> full planes)
         const bool zo_ok = s >= 2;
         const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res && fin ? HWR : 0u);
         const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok && fin ? HWO : 0u);
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
             //     MFMAs of slots 4..8 that could cover it (in the one-group kernel every slot has one) -- at 16 registers for U.
             //     The dz = 0 rows open a new output plane in the FIRST cin group (from 0; point (1,1) enters all four outputs
             //     with weight +1 and carries the bias) and continue it in the others.
-            const bool active = !DZ0 || dz == 0;
+            const bool active = ROWS == 0 || (ROWS == 1 && dz == 0) || (ROWS == 2 && dz <= 1);
             const int jn = j == 11 ? J_FIRST_NEXT : j + 1, dzn = 2 - (jn >> 2), pyn = jn & 3;
             const unsigned urow = (j == 11 ? (ua ^ UTOG) : ua) + (unsigned)((dzn * 4 + pyn) * 4 * 1024);
             const bool INIT = first && dz == 0;      // (folds: first is a constant, dz follows from the unrolled j)
@@ -676,20 +679,22 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     };
 
     // one input plane = G micro-steps: first, (G - 2 middle ones: one body, looped), last
-    auto plane = [&](auto ph_tag, auto dz0_tag) __attribute__((always_inline)) {
-        step(ph_tag, std::true_type{}, std::false_type{}, dz0_tag);
+    auto plane = [&](auto ph_tag, auto rows_tag) __attribute__((always_inline)) {
+        step(ph_tag, std::true_type{}, std::false_type{}, rows_tag);
         if (G > 2) {
 #pragma nounroll
-            for (int k = 0; k < G - 2; ++k) step(ph_tag, std::false_type{}, std::false_type{}, dz0_tag);
+            for (int k = 0; k < G - 2; ++k) step(ph_tag, std::false_type{}, std::false_type{}, rows_tag);
         }
-        step(ph_tag, std::false_type{}, std::true_type{}, dz0_tag);
+        step(ph_tag, std::false_type{}, std::true_type{}, rows_tag);
     };
-    plane(std::integral_constant<int, 0>{}, std::true_type{});          // plane s = 0 (z = zb - 1): dz = 0 rows only
+    using R0 = std::integral_constant<int, 0>;
+    plane(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});      // plane s = 0 (z = zb - 1): dz = 0 rows only
+    plane(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});      // plane s = 1: dz = 1, 0 rows
 #pragma nounroll
-    for (int sp = 1; sp < nsteps; sp += 3) {                             // planes 1 .. nsteps - 1, phase = s mod 3
-        plane(std::integral_constant<int, 1>{}, std::false_type{});
-        if (sp + 1 < nsteps) plane(std::integral_constant<int, 2>{}, std::false_type{});
-        if (sp + 2 < nsteps) plane(std::integral_constant<int, 0>{}, std::false_type{});
+    for (int sp = 2; sp < nsteps; sp += 3) {                                         // planes 2 .. nsteps - 1, phase = s mod 3
+        plane(std::integral_constant<int, 2>{}, R0{});
+        if (sp + 1 < nsteps) plane(std::integral_constant<int, 0>{}, R0{});
+        if (sp + 2 < nsteps) plane(std::integral_constant<int, 1>{}, R0{});
     }
 }
 
