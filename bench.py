@@ -47,11 +47,11 @@ def wino_exec_factor(ch, d, batch, num_cu=256):
     outputs and z tap, times the input planes a slab marches.  z-split as in pcc_conv_wino (the split that gives every CU a
     workgroup).  16-channel kernel: a slab runs (2/3 if it starts at z = 0 else 1) + zlen - (1 if it ends at z = D) plane-equivalents
     of MFMA rows (padding planes are skipped, the head planes run only the rows that feed this slab); the multi-group kernels:
-    zlen + 1 per slab (head planes as above, the tail plane in full)."""
+    zlen + 1 per slab (head planes as above, the tail plane in full), and the padding plane behind the volume is not marched either."""
     zs, base = 1, batch * (d // 16) ** 2 * (ch // 16)
     while base * zs < num_cu and d % (zs * 2) == 0 and d // (zs * 2) >= (4 if ch >= 32 else 8):
         zs *= 2
-    planes = d + zs - 4.0 / 3.0 if ch == 16 else d + zs * 1.0
+    planes = d + zs - 4.0 / 3.0 if ch == 16 else d + zs - 1.0
     return 16.0 / 36.0 * planes / d
 
 

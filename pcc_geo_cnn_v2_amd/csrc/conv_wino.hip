@@ -546,7 +546,9 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
         constexpr int AF = PH;
         constexpr bool first = decltype(first_tag)::value, fin = decltype(fin_tag)::value;
         // ROWS: 0 = all 12 MFMA rows; 1 = plane 0 of the slab (zb - 1): dz = 0 rows only; 2 = plane 1: dz = 1 and dz = 0 rows (its
-        // dz = 2 rows would finish output plane zb - 1, which belongs to the slab below and is never stored)
+        // dz = 2 rows would finish output plane zb - 1, which belongs to the slab below and is never stored); 3 = the plane behind a
+        // slab that ends at z = D (zero padding): no matrix work, no input work -- only its LAST micro-step runs, to reduce and store
+        // output plane D - 1
         constexpr int ROWS = decltype(rows_tag)::value;
         constexpr int J_OWN = ROWS == 1 ? 8 : ROWS == 2 ? 4 : 0;                 // first active row of this plane's micro-steps
         constexpr int J_FIRST_NEXT = !fin ? J_OWN : ROWS == 1 ? 4 : 0;           // ... of the NEXT micro-step (plane 0 -> plane 1 -> full planes)
@@ -603,14 +605,15 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
             }
             __builtin_amdgcn_sched_barrier(0);
             // (3) everything else, as one block behind the MFMAs of the slot
-            if (j == 0) transform_y_row(Vc, Vn, 3);
+            if (ROWS == 3) {
+            } else if (j == 0) transform_y_row(Vc, Vn, 3);
             else if (j == 1) {
                 stage_tile(wr_off, s2, c2, tile_pl);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Vn[i] = ldsr(ra[i]);
             } else if (j == 2) transform_x_rows(Vn, 0, 2);
             else if (j == 3) transform_x_rows(Vn, 2, 4);
-            if (STREAM) {        // U[cn] -> the idle buffer: pieces 0..11 of this wave in slots 0, 2..4
+            if (STREAM && ROWS != 3) {        // U[cn] -> the idle buffer: pieces 0..11 of this wave in slots 0, 2..4
                 // (all 12 pieces are on their way by slot 4: the last ones then have 8 slots to land before the closing barrier waits for them)
                 if (j == 0) { stage_u(ub_next, cn, 0); stage_u(ub_next, cn, 1); stage_u(ub_next, cn, 2); }
                 else if (j >= 2 && j <= 4) { stage_u(ub_next, cn, 3 * j - 3); stage_u(ub_next, cn, 3 * j - 2); stage_u(ub_next, cn, 3 * j - 1); }
@@ -644,7 +647,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
                     for (int q = 2 * (j - 9); q < 2 * (j - 9) + 2; ++q) asm volatile("" ::"v"(ost[q]));
                 }
             }
-            if (j == 9) transform_y_row(Vc, Vn, 0);
+            if (ROWS == 3) {
+            } else if (j == 9) transform_y_row(Vc, Vn, 0);
             else if (j == 10) {
                 transform_y_row(Vc, Vn, 1);
 #pragma unroll
@@ -658,6 +662,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
         }
         // tile m+2 (slot 1) and the U pieces (slots 0..7) must have landed before the barrier publishes them; the only younger
         // memory operations are the four stores of a final micro-step
+        if (ROWS == 3) return;                            // (the last thing this workgroup does)
         if (fin) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4)
         else __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
         __syncthreads();
@@ -690,11 +695,21 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     using R0 = std::integral_constant<int, 0>;
     plane(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});      // plane s = 0 (z = zb - 1): dz = 0 rows only
     plane(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});      // plane s = 1: dz = 1, 0 rows
+    // a slab that ends at z = D does not march the padding plane behind it (wave-uniform, decided outside the MFMA stream)
+    const bool last_zero = zb + a.zlen == a.D;
+    const int nloop = nsteps - (last_zero ? 1 : 0);
 #pragma nounroll
-    for (int sp = 2; sp < nsteps; sp += 3) {                                         // planes 2 .. nsteps - 1, phase = s mod 3
+    for (int sp = 2; sp < nloop; sp += 3) {                                          // planes 2 .. nloop - 1, phase = s mod 3
         plane(std::integral_constant<int, 2>{}, R0{});
-        if (sp + 1 < nsteps) plane(std::integral_constant<int, 0>{}, R0{});
-        if (sp + 2 < nsteps) plane(std::integral_constant<int, 1>{}, R0{});
+        if (sp + 1 < nloop) plane(std::integral_constant<int, 0>{}, R0{});
+        if (sp + 2 < nloop) plane(std::integral_constant<int, 1>{}, R0{});
+    }
+    if (last_zero) {
+        using R3 = std::integral_constant<int, 3>;
+        const int ph = (nsteps - 1) % 3;
+        if (ph == 0) step(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{}, R3{});
+        else if (ph == 1) step(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{}, R3{});
+        else step(std::integral_constant<int, 2>{}, std::false_type{}, std::true_type{}, R3{});
     }
 }
 
