@@ -495,10 +495,14 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bias_l = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + 16 * cog + g * 4) : zero4;
 
-    // ---- prologue: tiles 0, 1 -> ring slots 0, 1; U[0] -> buffer 0 (G = 2: and U[1] -> buffer 1)
-    unsigned long long tile_pl = (unsigned long long)in_n + (unsigned long long)(long long)(zb - 1) * HWI;    // tile (plane 0, group 0)
-    stage_tile(0, 0, 0, tile_pl);
-    stage_tile(PLANE_BYTES, 0, 1, tile_pl + 64);
+    // A slab that starts at z = 0 does not march the padding plane below it: it starts at plane 1, whose dz = 1 rows then open
+    // their accumulators (wave-uniform, decided here, outside the MFMA stream).
+    const bool first_zero = zb == 0;
+    const int s0 = first_zero ? 1 : 0;
+    // ---- prologue: tiles 0, 1 (plane s0, groups 0, 1) -> ring slots 0, 1; U[0] -> buffer 0 (G = 2: and U[1] -> buffer 1)
+    unsigned long long tile_pl = (unsigned long long)in_n + (unsigned long long)(long long)(zb - 1 + s0) * HWI;    // tile (plane s0, group 0)
+    stage_tile(0, s0, 0, tile_pl);
+    stage_tile(PLANE_BYTES, s0, 1, tile_pl + 64);
     tile_pl += 128;                                                                                          // tile m = 2
     if (G == 2) tile_pl += HWI - 128;
 #pragma unroll
@@ -518,19 +522,19 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     transform_y_row(Vc, Vn, 1);
     transform_y_row(Vc, Vn, 2);
 #pragma unroll
-    for (int px = 0; px < 4; ++px) Ub[px] = ldsr(ua + (unsigned)(px * 1024));      // first plane: dz = 0 rows only, first row (dz 0, py 0)
+    for (int px = 0; px < 4; ++px) Ub[px] = ldsr(ua + (unsigned)((s0 * 16 + px) * 1024));      // first active row: (dz 0, py 0) of plane 0, (dz 1, py 0) of plane 1
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }
 #pragma unroll
     for (int i = 0; i < 16; ++i) ra[i] += (unsigned)PLANE_BYTES;      // -> the slot of tile 1
 
     // wave-uniform march state
-    int c = 0, s = 0;                        // cin group and input plane of the current micro-step m
-    int s2 = 2 / G, c2 = 2 % G;              // plane / cin group of tile m + 2 (its address: tile_pl)
+    int c = 0, s = s0;                       // cin group and input plane of the current micro-step m
+    int s2 = s0 + 2 / G, c2 = 2 % G;         // plane / cin group of tile m + 2 (its address: tile_pl)
     unsigned wr_off = 2u * PLANE_BYTES;      // ring slot of tile m + 2
     int rd_slot = 1;                         // ring slot of tile m + 1 (what ra[] points into)
-    unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;     // plane zo of plane s = 0
-    unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
+    unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2 + s0) * HWR;     // plane zo of plane s0
+    unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2 + s0) * HWO;
 
     // one micro-step.  PH = s mod 3 (accumulator rotation), FIRST / FIN = first / last cin group of the plane: all compile
     // time -- wave-uniform run-time branches around the slot pieces were measured at ~1000 cycles per micro-step (12 % of it:
@@ -550,7 +554,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
         // slab that ends at z = D (zero padding): no matrix work, no input work -- only its LAST micro-step runs, to reduce and store
         // output plane D - 1
         constexpr int ROWS = decltype(rows_tag)::value;
-        constexpr int J_OWN = ROWS == 1 ? 8 : ROWS == 2 ? 4 : 0;                 // first active row of this plane's micro-steps
+        // 4 = plane 1 of a slab that starts at z = 0 (plane 0 skipped): as 2, and its dz = 1 rows OPEN their accumulators
+        constexpr int J_OWN = ROWS == 1 ? 8 : (ROWS == 2 || ROWS == 4) ? 4 : 0;  // first active row of this plane's micro-steps
         constexpr int J_FIRST_NEXT = !fin ? J_OWN : ROWS == 1 ? 4 : 0;           // ... of the NEXT micro-step (plane 0 -> plane 1 -> full planes)
         const bool zo_ok = s >= 2;
         const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res && fin ? HWR : 0u);
@@ -571,10 +576,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
             //     MFMAs of slots 4..8 that could cover it (in the one-group kernel every slot has one) -- at 16 registers for U.
             //     The dz = 0 rows open a new output plane in the FIRST cin group (from 0; point (1,1) enters all four outputs
             //     with weight +1 and carries the bias) and continue it in the others.
-            const bool active = ROWS == 0 || (ROWS == 1 && dz == 0) || (ROWS == 2 && dz <= 1);
+            const bool active = ROWS == 0 || (ROWS == 1 && dz == 0) || ((ROWS == 2 || ROWS == 4) && dz <= 1);
             const int jn = j == 11 ? J_FIRST_NEXT : j + 1, dzn = 2 - (jn >> 2), pyn = jn & 3;
             const unsigned urow = (j == 11 ? (ua ^ UTOG) : ua) + (unsigned)((dzn * 4 + pyn) * 4 * 1024);
-            const bool INIT = first && dz == 0;      // (folds: first is a constant, dz follows from the unrolled j)
+            const bool INIT = first && (dz == 0 || (ROWS == 4 && dz == 1));      // (folds: first is a constant, dz follows from the unrolled j)
             auto half = [&](auto h_tag) __attribute__((always_inline)) {
                 constexpr int PX0 = decltype(h_tag)::value * 2;
 #pragma unroll
@@ -693,8 +698,11 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
         step(ph_tag, std::false_type{}, std::true_type{}, rows_tag);
     };
     using R0 = std::integral_constant<int, 0>;
-    plane(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});      // plane s = 0 (z = zb - 1): dz = 0 rows only
-    plane(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});      // plane s = 1: dz = 1, 0 rows
+    if (first_zero) plane(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});      // plane s = 1 opens everything
+    else {
+        plane(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});      // plane s = 0 (z = zb - 1): dz = 0 rows only
+        plane(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});      // plane s = 1: dz = 1, 0 rows
+    }
     // a slab that ends at z = D does not march the padding plane behind it (wave-uniform, decided outside the MFMA stream)
     const bool last_zero = zb + a.zlen == a.D;
     const int nloop = nsteps - (last_zero ? 1 : 0);
