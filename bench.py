@@ -46,12 +46,12 @@ def wino_exec_factor(ch, d, batch, num_cu=256):
     """Executed / direct-convolution MFMA flops of a k3 stride-1 layer on csrc/conv_wino.hip: 16 instead of 36 multiplies per 2x2
     outputs and z tap, times the input planes a slab marches.  z-split as in pcc_conv_wino (the split that gives every CU a
     workgroup).  A slab runs (2/3 if it starts at z = 0 else 1) + zlen - (1 if it ends at z = D) plane-equivalents of MFMA rows:
-    padding planes are not marched, the two head planes run only the rows that feed this slab, a tail plane inside the volume is a
-    full step."""
+    padding planes are not marched, the two head planes run only the rows that feed this slab; a tail plane inside the volume is a
+    full step in the 16-channel kernel and a third of one (its dz = 2 rows) in the multi-group kernels."""
     zs, base = 1, batch * (d // 16) ** 2 * (ch // 16)
     while base * zs < num_cu and d % (zs * 2) == 0 and d // (zs * 2) >= (4 if ch >= 32 else 8):
         zs *= 2
-    planes = d + zs - 4.0 / 3.0
+    planes = d + zs - 4.0 / 3.0 if ch == 16 else d + (zs - 2.0) / 3.0
     return 16.0 / 36.0 * planes / d
 
 

@@ -541,10 +541,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
     // every taken branch restarts the instruction fetch), more than the epilogue they skip.
     // The two head planes of a slab run only the MFMA rows that feed ITS output planes (ROWS below): plane 0 (zb - 1) its dz = 0 rows,
     // plane 1 its dz = 1 and dz = 0 rows (the rest of the step -- staging, input transform -- is unchanged): 10 -> 9 plane-equivalents
-    // per 8-plane slab (64 -> 64 @16^3), 34 -> 33 (32 -> 32 @32^3).  The mirror image for the last plane (dz = 2 rows only) was built
-    // too: as compile-time bodies its extra control flow around 192 live accumulator registers made the allocator spill (90 - 780
-    // registers, whatever the loop shape), as a run-time row mask the 12 scalar branches per micro-step cost the 32-channel layer
-    // more (+7 % wave cycles) than the plane saves.
+    // per 8-plane slab (64 -> 64 @16^3), 34 -> 33 (32 -> 32 @32^3).  The mirror image for the plane behind the slab (ROWS 3 / 5) is a
+    // tail peeled off the loop, one variant per accumulator phase; earlier attempts that kept it inside the loop structure made the
+    // allocator spill 90 - 780 registers, and a run-time row mask cost the 32-channel layer more (+7 % wave cycles, 12 scalar branches
+    // per micro-step) than the plane saves.
     auto step = [&](auto ph_tag, auto first_tag, auto fin_tag, auto rows_tag) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr int AF = PH;
@@ -555,6 +555,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
         // output plane D - 1
         constexpr int ROWS = decltype(rows_tag)::value;
         // 4 = plane 1 of a slab that starts at z = 0 (plane 0 skipped): as 2, and its dz = 1 rows OPEN their accumulators
+        // 5 = the plane behind a slab INSIDE the volume (zb + zlen): only its dz = 2 rows feed this slab (output plane zb + zlen - 1)
         constexpr int J_OWN = ROWS == 1 ? 8 : (ROWS == 2 || ROWS == 4) ? 4 : 0;  // first active row of this plane's micro-steps
         constexpr int J_FIRST_NEXT = !fin ? J_OWN : ROWS == 1 ? 4 : 0;           // ... of the NEXT micro-step (plane 0 -> plane 1 -> full planes)
         const bool zo_ok = s >= 2;
@@ -576,9 +577,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
             //     MFMAs of slots 4..8 that could cover it (in the one-group kernel every slot has one) -- at 16 registers for U.
             //     The dz = 0 rows open a new output plane in the FIRST cin group (from 0; point (1,1) enters all four outputs
             //     with weight +1 and carries the bias) and continue it in the others.
-            const bool active = ROWS == 0 || (ROWS == 1 && dz == 0) || ((ROWS == 2 || ROWS == 4) && dz <= 1);
-            const int jn = j == 11 ? J_FIRST_NEXT : j + 1, dzn = 2 - (jn >> 2), pyn = jn & 3;
-            const unsigned urow = (j == 11 ? (ua ^ UTOG) : ua) + (unsigned)((dzn * 4 + pyn) * 4 * 1024);
+            const bool active = ROWS == 0 || (ROWS == 1 && dz == 0) || ((ROWS == 2 || ROWS == 4) && dz <= 1) || (ROWS == 5 && dz == 2);
+            constexpr int J_LAST = ROWS == 5 ? 3 : 11;       // last active row: its U prefetch is the next micro-step's first row
+            const int jn = j == J_LAST ? J_FIRST_NEXT : j + 1, dzn = 2 - (jn >> 2), pyn = jn & 3;
+            const unsigned urow = (j == J_LAST ? (ua ^ UTOG) : ua) + (unsigned)((dzn * 4 + pyn) * 4 * 1024);
             const bool INIT = first && (dz == 0 || (ROWS == 4 && dz == 1));      // (folds: first is a constant, dz follows from the unrolled j)
             auto half = [&](auto h_tag) __attribute__((always_inline)) {
                 constexpr int PX0 = decltype(h_tag)::value * 2;
@@ -591,7 +593,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
                     }
             };
             auto next_u = [&](int px0) __attribute__((always_inline)) {
-                if (j < 11 || !STREAM) {
+                if (j < J_LAST || !STREAM) {
                     Ub[px0] = ldsr(urow + (unsigned)(px0 * 1024));
                     Ub[px0 + 1] = ldsr(urow + (unsigned)((px0 + 1) * 1024));
                 }
@@ -601,7 +603,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
                 next_u(0);
                 half(std::integral_constant<int, 1>{});
                 next_u(2);
-                if (j < 11 || !STREAM) {
+                if (j < J_LAST || !STREAM) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
@@ -703,21 +705,27 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_cin_kernel(WinoArgs a, int 
         plane(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});      // plane s = 0 (z = zb - 1): dz = 0 rows only
         plane(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});      // plane s = 1: dz = 1, 0 rows
     }
-    // a slab that ends at z = D does not march the padding plane behind it (wave-uniform, decided outside the MFMA stream)
+    // The plane behind the slab is peeled off the loop: behind the volume (z = D, zero padding) only the reduction + store of output
+    // plane D - 1 is left of it; inside the volume only its dz = 2 rows feed this slab.  Wave-uniform, decided outside the MFMA stream.
     const bool last_zero = zb + a.zlen == a.D;
-    const int nloop = nsteps - (last_zero ? 1 : 0);
+    const int nloop = nsteps - 1;
 #pragma nounroll
     for (int sp = 2; sp < nloop; sp += 3) {                                          // planes 2 .. nloop - 1, phase = s mod 3
         plane(std::integral_constant<int, 2>{}, R0{});
         if (sp + 1 < nloop) plane(std::integral_constant<int, 0>{}, R0{});
         if (sp + 2 < nloop) plane(std::integral_constant<int, 1>{}, R0{});
     }
+    using R3 = std::integral_constant<int, 3>;
+    using R5 = std::integral_constant<int, 5>;
+    const int ph = (nsteps - 1) % 3;
     if (last_zero) {
-        using R3 = std::integral_constant<int, 3>;
-        const int ph = (nsteps - 1) % 3;
         if (ph == 0) step(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{}, R3{});
         else if (ph == 1) step(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{}, R3{});
         else step(std::integral_constant<int, 2>{}, std::false_type{}, std::true_type{}, R3{});
+    } else {
+        if (ph == 0) plane(std::integral_constant<int, 0>{}, R5{});
+        else if (ph == 1) plane(std::integral_constant<int, 1>{}, R5{});
+        else plane(std::integral_constant<int, 2>{}, R5{});
     }
 }
 
