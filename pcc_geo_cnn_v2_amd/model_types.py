@@ -781,7 +781,8 @@ class CompressionModelV1(CompressionModel):
         stg = self._staging(ctx, slot, B, [v // 8 for v in x.shape[1:4]])
         if codec is not None:                      # analysis -> quantise -> synthesis (-> fixed threshold) in one ABI call
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(ctx.device))      # creates the handle; re-recorded by the library
+            ready.record(self._side_stream(ctx, '_idx_stream'))      # creates the handle (on a stream that is idle now: a record costs the
+                                                                     # main queue a few microseconds); re-recorded by the library on the main stream
             t = ops.codec_encode(ctx, codec, x.contiguous(), thr, symbols_ready=ready, staging=stg)
             y, ysym, y_hat, x_hat = t['y'], t['symbols'], t['y_hat'], t['x_hat']
         else:
@@ -908,7 +909,8 @@ class CompressionModelV2(CompressionModel):
         stg = self._staging(ctx, slot, B, [v // 8 for v in x.shape[1:4]], [v // 16 for v in x.shape[1:4]])
         if codec is not None:                      # the whole GPU part of compress() (model_types.py:379-388) in one ABI call
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(ctx.device))      # creates the handle; re-recorded by the library
+            ready.record(self._side_stream(ctx, '_idx_stream'))      # creates the handle (on a stream that is idle now: a record costs the
+                                                                     # main queue a few microseconds); re-recorded by the library on the main stream
             t = ops.codec_encode(ctx, codec, x.contiguous(), thr, symbols_ready=ready, staging=stg)
             y, z, zsym, z_hat, sigma, idx, ysym, y_hat, x_hat = (t[k] for k in ('y', 'z', 'z_symbols', 'z_hat', 'sigma_hat',
                                                                                 'indexes', 'symbols', 'y_hat', 'x_hat'))
