@@ -215,7 +215,9 @@ int pcc_codec_decode_main(pcc_ctx* ctx, const pcc_codec_desc* c, int32_t* ysym, 
 
 /* Live kernel timing: HIP events recorded on the launch stream around layer `layer` of transform `transform` in every
  * pcc_network_forward / pcc_codec_* call (transform < 0 switches it off); pcc_profile_read waits for the recorded events,
- * returns their durations in milliseconds (at most `cap`) and clears the list.  The events belong to the context.        */
+ * returns their durations in milliseconds (at most `cap`) and clears the list.  The events belong to the context.
+ * `layer` = index | (stride << 16): with stride > 1 only every stride-th call of the layer is timed (an event record costs the
+ * queue a few microseconds: sampling keeps the measurement from slowing what it measures).                               */
 int pcc_profile_select(pcc_ctx* ctx, int32_t transform, int32_t layer);
 int pcc_profile_read(pcc_ctx* ctx, float* ms, int32_t cap, int32_t* n);
 

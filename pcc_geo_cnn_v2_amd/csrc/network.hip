@@ -124,6 +124,8 @@ size_t act_floats(const std::vector<LayerSpec>& v, int N, int D, int H, int W) {
 
 struct Profile {
     int transform = -1, layer = -1;
+    int stride = 1;                 // every stride-th call of the selected layer is timed (the event records cost the queue ~6 us each)
+    unsigned calls = 0;
     std::vector<hipEvent_t> ev;     // pairs (start, stop)
     size_t used = 0;
 };
@@ -320,7 +322,7 @@ static int network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, con
             while (cur == in_buf || cur == t1_buf) cur = (cur + 1) % 3;
             out = buf[cur];
         }
-        const bool timed = prof && prof->transform == transform && prof->layer == (int)i;
+        const bool timed = prof && prof->transform == transform && prof->layer == (int)i && (prof->calls++ % (unsigned)prof->stride) == 0;
         if (timed) {
             if (prof->used + 2 > prof->ev.size()) {
                 PCC_REQUIRE(prof->ev.size() < 8192, "pcc_network_forward: profile buffer full (pcc_profile_read drains it)");
@@ -367,7 +369,7 @@ PCC_API int pcc_profile_select(pcc_ctx* ctx, int32_t transform, int32_t layer) {
     PCC_REQUIRE(ctx, "pcc_profile_select: ctx is NULL");
     if (transform < 0) { if (ctx->profile) { Profile* p = (Profile*)ctx->profile; p->transform = p->layer = -1; p->used = 0; } return PCC_OK; }
     Profile* p = prof_of(ctx);
-    p->transform = transform; p->layer = layer; p->used = 0;
+    p->transform = transform; p->layer = layer & 0xffff; p->stride = (layer >> 16) > 0 ? (layer >> 16) : 1; p->calls = 0; p->used = 0;
     return PCC_OK;
 }
 

@@ -445,8 +445,9 @@ def codec_decode_main(ctx, desc, ysym, dhw, thr=None, cap=None, packed=None, cha
     return t
 
 
-def profile_select(ctx, transform, layer):
-    L.check(L.lib().pcc_profile_select(ctx.handle, transform, layer), 'pcc_profile_select')
+def profile_select(ctx, transform, layer, stride=1):
+    """Live HIP-event timing of one layer of one transform inside the graph calls; stride > 1 times every stride-th call only."""
+    L.check(L.lib().pcc_profile_select(ctx.handle, transform, layer | (int(stride) << 16) if transform >= 0 else layer), 'pcc_profile_select')
 
 
 def profile_read(ctx, cap=8192):
