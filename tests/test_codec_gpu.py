@@ -437,3 +437,26 @@ def test_last_layer_writes_the_occupancy_bits_of_the_fixed_threshold(ctx, res, b
     d = ops.codec_decode_main(mc, m._codec(mc), e['symbols'], [res] * 3, thr, scratch=s2)
     assert torch.equal(d['x_hat'], e['x_hat'])
     check(d, s2, False)
+
+
+def test_graph_packs_symbols_and_rows_exactly_as_the_stand_alone_kernels(ctx):
+    """pcc_codec_encode folds the quantisers and the sigma -> CDF-row step into its pack launches (binary search on the ascending
+    scale table the reference builds, patch_gaussian_conditional.py:104-116): the int32 tensors it returns must be what
+    pcc_scale_to_index gives on the same sigma_hat, and the staging buffer must hold exactly their stream-order permutation in the
+    narrow integer types, with the true max|symbol| in the tile maxima."""
+    g = torch.Generator().manual_seed(9)
+    m = ModelConfigType['c3p'].build(batch_size=2)
+    m.compress([1, 1, 32, 32, 32])
+    m.set_weights(scaled_weights(m, 2.2))
+    mc = m._ctx(ctx)
+    x = (torch.rand((2, 32, 32, 32), generator=g) < 0.05).float().to(ctx.device)
+    stg = m._staging(mc, 7, 2, [4, 4, 4], [2, 2, 2])
+    t = ops.codec_encode(mc, m._codec(mc), x, None, staging=stg)
+    tab = m._dev(mc, 'scale_table', m.conditional_bottleneck.scale_table_f32)
+    assert torch.equal(t['indexes'], ops.scale_to_index(mc, t['sigma_hat'], tab))
+    stg.copy_out()
+    torch.cuda.synchronize()
+    assert torch.equal(stg.idx, t['indexes'].permute(0, 4, 1, 2, 3).contiguous().to(torch.uint8).cpu())
+    assert torch.equal(stg.ysym, t['symbols'].permute(0, 4, 1, 2, 3).contiguous().to(torch.int16).cpu())
+    assert torch.equal(stg.zsym, t['z_symbols'].permute(0, 4, 1, 2, 3).contiguous().to(torch.int16).cpu())
+    assert int(stg.ytm.max()) == int(t['symbols'].abs().max()) and int(stg.ztm.max()) == int(t['z_symbols'].abs().max())

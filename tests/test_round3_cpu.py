@@ -271,3 +271,18 @@ def test_usable_cores_respects_affinity_and_quota(monkeypatch, tmp_path):
     assert ops.usable_cores() == min(2, len(os.sched_getaffinity(0)))
     monkeypatch.setattr(builtins, 'open', fake('max 100000\n'))
     assert ops.usable_cores() == len(os.sched_getaffinity(0))
+
+
+def test_package_asks_for_eight_hardware_queues_before_the_runtime_loads():
+    """The copy streams need hardware queues of their own beside RCCL's streams: the package sets
+    GPU_MAX_HW_QUEUES unless the caller already did."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = 'import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import pcc_geo_cnn_v2_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
+    assert out == '8'
+    code = 'import os; os.environ["GPU_MAX_HW_QUEUES"] = "5"; import pcc_geo_cnn_v2_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
+    assert out == '5'
