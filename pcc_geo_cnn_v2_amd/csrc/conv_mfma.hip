@@ -1061,6 +1061,34 @@ __global__ void __launch_bounds__((Cin1Cfg<COUT, KS, TZ, TY, R>::NT)) conv_cin1_
     const int iz0 = oz0 * 2 - C::PL, iy0 = oy0 * 2 - C::PL, ix0 = ox0 * 2 - C::PL;
 
     const float* inb = a.in + (size_t)n * a.D * a.H * a.W;
+    if constexpr (KS == 3) {
+        // k3: no low-side halo (PL = 0) and ix0 = 32 tx, so a row of the tile is 9 aligned float4 of one image row: all loads of a
+        // thread are in flight together (the scalar loop below spent ~50 VALU instructions per element on index arithmetic: the
+        // kernel was VALU-bound at 0.14 of the MFMA peak with its matrix pipe 4 % busy)
+        constexpr int Q = (C::LXU + 3) / 4, ROWS = C::LZ * C::LY, NITEM = ROWS * Q, PER = (NITEM + C::NT - 1) / C::NT;
+        const size_t img = (size_t)a.D * a.H * a.W;
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)(img * 4));       // (the planner admits < 2 GiB per image)
+        f32x4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int it = i * C::NT + tid, row = it / Q, q = it - row * Q;
+            const int lz = row / C::LY, ly = row - lz * C::LY;
+            const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + 4 * q;
+            const bool ok = it < NITEM && gz < a.D && gy < a.H && gx < a.W;
+            v[i] = buf_load4(rin, ok ? (unsigned)((((size_t)gz * a.H + gy) * a.W + gx) * 4) : kOOB, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int it = i * C::NT + tid, row = it / Q, q = it - row * Q;
+            if (it < NITEM) {
+                float* lp = lds + row * C::LX + 4 * q;
+                const int gx = ix0 + 4 * q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < C::LX) lp[e] = (gx + e < a.W) ? v[i][e] : 0.f;       // beyond the image row: SAME padding
+            }
+        }
+    } else {
 #pragma unroll 1
     for (int it = 0; it < C::ITEMS; ++it) {
         const int u = it * C::NT + tid;
@@ -1071,6 +1099,7 @@ __global__ void __launch_bounds__((Cin1Cfg<COUT, KS, TZ, TY, R>::NT)) conv_cin1_
             const bool ok = gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             lds[u] = ok ? inb[((size_t)gz * a.H + gy) * a.W + gx] : 0.f;
         }
+    }
     }
     __syncthreads();
 
