@@ -286,3 +286,28 @@ def test_package_asks_for_eight_hardware_queues_before_the_runtime_loads():
     code = 'import os; os.environ["GPU_MAX_HW_QUEUES"] = "5"; import pcc_geo_cnn_v2_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
     out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
     assert out == '5'
+
+
+def test_bench_flop_model_reproduces_the_survey_and_the_kernel_row_counts():
+    """bench.py's layer walk must give SURVEY.md 8d's algorithmic flops per block (31.086 GFLOP, c3p @64^3) and an executed count
+    that follows conv_wino.hip's row skipping: 16 / 36 of the direct flops times (D + zs - 4/3) / D plane-equivalents for the
+    16-channel kernel, (D + (zs - 2) / 3) / D for the multi-group kernels."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv, sys.argv = sys.argv, ['bench.py']
+    try:
+        spec = importlib.util.spec_from_file_location('bench_module', os.path.join(root, 'bench.py'))
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    alg, ex = b.c3p_step_flops(64, 32)
+    assert abs(alg / 31.086e9 - 1) < 1e-3
+    assert 0.5 < ex / alg < 0.56
+    assert abs(b.wino_exec_factor(16, 64, 32) - 16 / 36 * (64 - 1 / 3) / 64) < 1e-12          # one whole-volume slab
+    assert abs(b.wino_exec_factor(64, 16, 32) - 16 / 36 * 16 / 16) < 1e-12                     # two 8-plane slabs at 8 plane-equivalents each
+    assert abs(b.wino_exec_factor(16, 32, 32) - 16 / 36 * (32 + 2 - 4 / 3) / 32) < 1e-12       # two 16-plane slabs
+    alg1, ex1 = b.c3p_step_flops(64, 32, winograd=False)
+    assert alg1 == alg and ex1 == alg
