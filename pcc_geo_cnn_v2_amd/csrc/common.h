@@ -88,6 +88,12 @@ void pcc_f16_pack(int C, const float* wlog, unsigned short* out);
 int pcc_conv_f16(pcc_ctx* ctx, const pcc_conv_desc* d, const void* in, const void* w_packed, const float* bias,
                  const void* residual, void* out, bool out32, hipStream_t st);
 constexpr int PCC_WINO_U_FLOATS = 48 * 64 * 4;   // per (cin group, cout group): [z tap][point][lane][cin quad member]
+// split-bf16 Winograd path (conv_wino_bf16.hip): the same U as three bf16 pieces, two MFMA operands of 16 B per (row, lane)
+constexpr int PCC_WINO_UB_FLOATS = 48 * 2 * 64 * 4;
+bool pcc_wino_bf16_covers(const pcc_conv_desc* d);      // (given pcc_wino_eligible)
+void pcc_wino_bf16_pack(int ngroups, const float* u_f32, float* out);
+int pcc_conv_wino_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* ub_packed, const float* bias,
+                       const float* residual, float* out, hipStream_t st);
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is set per DEVICE:
 // remember the (function, device) pairs this thread has configured.
 #include <utility>

@@ -1726,7 +1726,8 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
             // 16->16 / 32->32 k3 stride-1 layers also carry the Winograd-transformed weights (conv_wino.hip)
             if (pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && d->stride == 1)
                 return k3 * d->Cin * d->Cout + (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_U_FLOATS +
-                       pcc_f16_packed_bytes(d->Cin) / 4;     // + the fp16 fragments of conv_f16.hip
+                       pcc_f16_packed_bytes(d->Cin) / 4 +     // + the fp16 fragments of conv_f16.hip
+                       (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_UB_FLOATS;     // + the split-bf16 image of U (conv_wino_bf16.hip)
             return k3 * d->Cin * d->Cout;
         case K_TR2: return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1);     // k3: second copy in the order of conv_tr2g_kernel
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
@@ -1783,6 +1784,8 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                 pcc_f16_pack(Cin, wlog, (unsigned short*)(u + (size_t)NG * NCT * PCC_WINO_U_FLOATS));
                 free(wlog);
             }
+            // split-bf16 image of U behind the fp16 block
+            pcc_wino_bf16_pack(NG, u, u + (size_t)NG * NCT * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(Cin) / 4);
         }
     } else if (p.kind == K_TR2) {
         // consumption order of conv_tr2_kernel: [parity class (pz,py,px)][taps of the class (kz,ky,kx)][g][ct][lane][j]
@@ -1876,7 +1879,13 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
             static const bool no_wino32 = getenv("PCC_NO_WINOGRAD32") != nullptr;
             static const bool wino64 = getenv("PCC_NO_WINOGRAD64") == nullptr;
             const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !(d->flags & PCC_CONV_F16) && !no_wino && !(ci == 32 && (no_wino32 || d->D < 16)) && !(ci == 64 && !wino64));
-            if (want && pcc_wino_eligible(d)) return pcc_conv_wino(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, residual, out, st);
+            if (want && pcc_wino_eligible(d)) {
+                const float* u32 = w_packed + (size_t)27 * ci * co;
+                // split-bf16 operands on the bf16 MFMA pipe (fp32-equivalent, conv_wino_bf16.hip); PCC_NO_SPLIT=1: exact-fp32 MFMA (A/B)
+                const bool split = getenv("PCC_NO_SPLIT") == nullptr && pcc_wino_bf16_covers(d);     // (read per call: tests flip it)
+                if (split) return pcc_conv_wino_bf16(ctx, d, in, u32 + (size_t)(ci / 16) * (co / 16) * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(ci) / 4, bias, residual, out, st);
+                return pcc_conv_wino(ctx, d, in, u32, bias, residual, out, st);
+            }
             PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD needs W and H multiples of 16");
         } else {
             PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD covers Cin = Cout in {16,32,64} k3 stride-1 layers only");
