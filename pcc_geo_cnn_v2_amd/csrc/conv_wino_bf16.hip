@@ -31,9 +31,17 @@
 #include <cstring>
 #include "wino_common.h"
 
+// timing probes (tools/build_variant.sh): 1 no step barrier / vmcnt wait, 2 no plane loads, 4 no residual loads / stores, 8 no DOT
+// blocks, 16 no MFMAs, 32 no cvts, 64 no output side (AccVGPR reads, A^T, epilogue), 128 no input transforms,
+// 256 no U refills, 512 no patch reads, 1024 AccVGPR reads in the K blocks
+#ifndef PCC_WB_PROBE
+#define PCC_WB_PROBE 0
+#endif
+
 namespace pccwino {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int UB_ROW_BYTES = 2048;                       // per (dz, point): A1 = [Uh | Um] (64 lanes x 16 B), A2 = [Ul | Uh]
 constexpr int UB_BYTES = 48 * UB_ROW_BYTES;              // 98304
@@ -42,29 +50,22 @@ constexpr int LDS_BYTES_B = U_BASE + UB_BYTES;           // 162816 <= 160 KB
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// Two Winograd points (2 x 4 input channels of one tile): fp32 -> B1 = [Vh | Vm], B2 = [Vl | Vh] each.  ONE asm block, because
-// v_dot2c_f32_bf16 is a DOT instruction: a different VALU op that reads its result needs 3 wait states behind it
-// (GCNHazardRecognizer: DotWriteDifferentVALURead) and the hazard recogniser cannot see into inline asm.  Inside the block every
-// reader sits >= 3 instructions behind its writer; K0 / K1 = the bf16 pairs {-1, 0} / {0, -1}: x -= lo(h) / hi(h), exactly.
-__device__ __forceinline__ void split_points2(u32x4& p_b1, u32x4& p_b2, u32x4& q_b1, u32x4& q_b2, const f32x4& pv, const f32x4& qv) {
-    float a = pv[0], b = pv[1], c = pv[2], d = pv[3], e = qv[0], f = qv[1], g = qv[2], h = qv[3];
-    unsigned ph01, ph23, pm01, pm23, pl01, pl23, pg01, pg23, qh01, qh23, qm01, qm23, ql01, ql23, qg01, qg23;
+// Y -= bf16 piece pairs p0..p7 (pair j covers Y[2j], Y[2j+1]), exactly.  v_dot2c_f32_bf16 is a DOT instruction: another VALU op
+// that reads its result needs 3 wait states behind it (GCNHazardRecognizer: DotWriteDifferentVALURead), which the hazard
+// recogniser cannot see in inline asm -- the block ends with them.  K0 / K1 = the bf16 pairs {-1, 0} / {0, -1}: x -= lo(p) / hi(p).
+__device__ __forceinline__ void dot2c_sub16(float (&Y)[16], unsigned p0, unsigned p1, unsigned p2, unsigned p3, unsigned p4, unsigned p5,
+                                            unsigned p6, unsigned p7) {
     asm volatile(
-        "v_cvt_pk_bf16_f32 %8, %0, %1\n\tv_cvt_pk_bf16_f32 %9, %2, %3\n\tv_cvt_pk_bf16_f32 %16, %4, %5\n\tv_cvt_pk_bf16_f32 %17, %6, %7\n\t"
-        "v_cvt_pk_bf16_f32 %14, %0, %1\n\tv_cvt_pk_bf16_f32 %15, %2, %3\n\tv_cvt_pk_bf16_f32 %22, %4, %5\n\tv_cvt_pk_bf16_f32 %23, %6, %7\n\t"
-        "v_dot2c_f32_bf16 %0, %24, %8\n\tv_dot2c_f32_bf16 %1, %25, %8\n\tv_dot2c_f32_bf16 %2, %24, %9\n\tv_dot2c_f32_bf16 %3, %25, %9\n\t"
-        "v_dot2c_f32_bf16 %4, %24, %16\n\tv_dot2c_f32_bf16 %5, %25, %16\n\tv_dot2c_f32_bf16 %6, %24, %17\n\tv_dot2c_f32_bf16 %7, %25, %17\n\t"
-        "v_cvt_pk_bf16_f32 %10, %0, %1\n\tv_cvt_pk_bf16_f32 %11, %2, %3\n\tv_cvt_pk_bf16_f32 %18, %4, %5\n\ts_nop 0\n\tv_cvt_pk_bf16_f32 %19, %6, %7\n\t"
-        "v_dot2c_f32_bf16 %0, %24, %10\n\tv_dot2c_f32_bf16 %1, %25, %10\n\tv_dot2c_f32_bf16 %2, %24, %11\n\tv_dot2c_f32_bf16 %3, %25, %11\n\t"
+        "v_dot2c_f32_bf16 %0, %24, %16\n\tv_dot2c_f32_bf16 %1, %25, %16\n\tv_dot2c_f32_bf16 %2, %24, %17\n\tv_dot2c_f32_bf16 %3, %25, %17\n\t"
         "v_dot2c_f32_bf16 %4, %24, %18\n\tv_dot2c_f32_bf16 %5, %25, %18\n\tv_dot2c_f32_bf16 %6, %24, %19\n\tv_dot2c_f32_bf16 %7, %25, %19\n\t"
-        "v_cvt_pk_bf16_f32 %12, %0, %1\n\tv_cvt_pk_bf16_f32 %13, %2, %3\n\tv_cvt_pk_bf16_f32 %20, %4, %5\n\ts_nop 0\n\tv_cvt_pk_bf16_f32 %21, %6, %7\n\ts_nop 2"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h),
-          "=&v"(ph01), "=&v"(ph23), "=&v"(pm01), "=&v"(pm23), "=&v"(pl01), "=&v"(pl23), "=&v"(pg01), "=&v"(pg23),
-          "=&v"(qh01), "=&v"(qh23), "=&v"(qm01), "=&v"(qm23), "=&v"(ql01), "=&v"(ql23), "=&v"(qg01), "=&v"(qg23)
-        : "s"(0x0000bf80u), "s"(0xbf800000u));
-    p_b1 = (u32x4){ph01, ph23, pm01, pm23}; p_b2 = (u32x4){pl01, pl23, pg01, pg23};
-    q_b1 = (u32x4){qh01, qh23, qm01, qm23}; q_b2 = (u32x4){ql01, ql23, qg01, qg23};
+        "v_dot2c_f32_bf16 %8, %24, %20\n\tv_dot2c_f32_bf16 %9, %25, %20\n\tv_dot2c_f32_bf16 %10, %24, %21\n\tv_dot2c_f32_bf16 %11, %25, %21\n\t"
+        "v_dot2c_f32_bf16 %12, %24, %22\n\tv_dot2c_f32_bf16 %13, %25, %22\n\tv_dot2c_f32_bf16 %14, %24, %23\n\tv_dot2c_f32_bf16 %15, %25, %23\n\ts_nop 2"
+        : "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]), "+v"(Y[6]), "+v"(Y[7]),
+          "+v"(Y[8]), "+v"(Y[9]), "+v"(Y[10]), "+v"(Y[11]), "+v"(Y[12]), "+v"(Y[13]), "+v"(Y[14]), "+v"(Y[15])
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "s"(0x0000bf80u), "s"(0xbf800000u));
 }
+__device__ __forceinline__ void acc_read1(float& d, const float& a) { asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d) : "a"(a)); }
+
 // B^T along x on one patch row (4 voxels x 4 channels), in place
 __device__ __forceinline__ void transform_x_row(f32x4 (&P)[4]) {
     const f32x4 d0 = P[0], d1 = P[1], d2 = P[2], d3 = P[3];
@@ -81,6 +82,12 @@ __device__ __forceinline__ unsigned park(unsigned v) {
 __device__ __forceinline__ unsigned unpark(unsigned a) {
     unsigned v;
     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+// a parked LDS address: below the plane size, so that base + ring-slot offset folds into the DS offset field
+__device__ __forceinline__ unsigned unpark_lds(unsigned a) {
+    const unsigned v = unpark(a);
+    __builtin_assume(v < (unsigned)PLANE_BYTES + 4096u);
     return v;
 }
 
@@ -120,6 +127,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
     const int t = lane & 15, g = lane >> 4;
     auto ldsr = [&](unsigned off) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + off); };
     auto ldsu = [&](unsigned off) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + off); };
+    typedef const f32x4 __attribute__((address_space(3)))* lds_cf4;
+    auto lds_abs = [&](unsigned addr) -> f32x4 { return *(lds_cf4)(unsigned long long)addr; };     // absolute LDS address
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
     int wg = xcd_remap(blockIdx.x, nwg);
@@ -201,19 +210,36 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
     __syncthreads();
 
     u32x4 B1[16], B2[16];       // pieces of B^T d B of the current input plane: [Vh | Vm], [Vl | Vh]
-    f32x4 P0[4], P1[4], P2[4], P3[4];      // x-transformed patch rows of the NEXT plane (at most three are live)
+    f32x4 P0[4], P1[4], P2[4], P3[4];      // x-transformed patch rows of the NEXT plane (two are live at a time)
+    float Y[16];                // fp32 row of V on its way through the split: (point x, channel c) at 4x + c
+    float Mr[16];               // accumulators of the finished plane's row on their way through A^T
     u32x4 A1[4], A2[4];         // U fragments of the row in flight: [Uh | Um], [Ul | Uh] per point px
     f32x4 acc[3][16];           // three output planes in flight
     f32x4 S[2][2];
     f32x4 resv[4], ost[4];
-    // V row r of the plane whose patch rows are in P*: y-transform + split
-    auto vrow = [&](auto r_tag) __attribute__((always_inline)) {
+    // ---- pieces of the schedule.  V row r of a plane: Y = its fp32 values (yrow), then H = cvt(Y), Y -= H, M = cvt(Y), Y -= M,
+    //      L = cvt(Y).  The cvts are single VALU ops the compiler sees (fillers between MFMAs); the subtractions are asm blocks.
+    auto yrow = [&](auto r_tag) __attribute__((always_inline)) {
         constexpr int r = decltype(r_tag)::value;
-        f32x4 y[4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) y[x] = r == 0 ? sub4(P0[x], P2[x]) : r == 1 ? add4(P1[x], P2[x]) : r == 2 ? sub4(P2[x], P1[x]) : sub4(P1[x], P3[x]);
-        split_points2(B1[r * 4 + 0], B2[r * 4 + 0], B1[r * 4 + 1], B2[r * 4 + 1], y[0], y[1]);
-        split_points2(B1[r * 4 + 2], B2[r * 4 + 2], B1[r * 4 + 3], B2[r * 4 + 3], y[2], y[3]);
+        for (int x = 0; x < 4; ++x) {
+            const f32x4 y = r == 0 ? sub4(P0[x], P2[x]) : r == 1 ? add4(P1[x], P2[x]) : r == 2 ? sub4(P2[x], P1[x]) : sub4(P1[x], P3[x]);
+            Y[4 * x + 0] = y[0]; Y[4 * x + 1] = y[1]; Y[4 * x + 2] = y[2]; Y[4 * x + 3] = y[3];
+        }
+    };
+    // pair j = (point x = j >> 1, channel pair hf = j & 1) of row r: stage 0 = h (also into B2), 1 = m, 2 = l
+    auto cvt_task = [&](auto r_tag, auto st_tag, auto j_tag) __attribute__((always_inline)) {
+        constexpr int r = decltype(r_tag)::value, st = decltype(st_tag)::value, j = decltype(j_tag)::value;
+        constexpr int x = j >> 1, hf = j & 1;
+        const unsigned v = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){Y[4 * x + 2 * hf], Y[4 * x + 2 * hf + 1]}, bf16x2));
+        if (st == 0) { B1[r * 4 + x][hf] = v; B2[r * 4 + x][2 + hf] = v; }
+        else if (st == 1) B1[r * 4 + x][2 + hf] = v;
+        else B2[r * 4 + x][hf] = v;
+    };
+    auto dot_block = [&](auto r_tag, auto st_tag) __attribute__((always_inline)) {      // Y -= piece `st` (0: h, 1: m) of row r
+        constexpr int r = decltype(r_tag)::value, o = decltype(st_tag)::value == 0 ? 0 : 2;
+        dot2c_sub16(Y, B1[r * 4 + 0][o], B1[r * 4 + 0][o + 1], B1[r * 4 + 1][o], B1[r * 4 + 1][o + 1], B1[r * 4 + 2][o], B1[r * 4 + 2][o + 1],
+                    B1[r * 4 + 3][o], B1[r * 4 + 3][o + 1]);
     };
     auto load_prow = [&](f32x4 (&P)[4], int dy, unsigned slot_off) __attribute__((always_inline)) {
 #pragma unroll
@@ -223,11 +249,24 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
     using R1 = std::integral_constant<int, 1>;
     using R2 = std::integral_constant<int, 2>;
     using R3 = std::integral_constant<int, 3>;
+    using ST0 = std::integral_constant<int, 0>;
+    using ST1 = std::integral_constant<int, 1>;
+    using ST2 = std::integral_constant<int, 2>;
+    // a whole row at once (prologue only)
+    auto split_row = [&](auto r_tag) __attribute__((always_inline)) {
+        yrow(r_tag);
+        static_for<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(r_tag, ST0{}, j); });
+        dot_block(r_tag, ST0{});
+        static_for<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(r_tag, ST1{}, j); });
+        dot_block(r_tag, ST1{});
+        static_for<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(r_tag, ST2{}, j); });
+    };
     {
         const unsigned so = (unsigned)s0 * PLANE_BYTES;
         load_prow(P0, 0, so); load_prow(P1, 1, so); load_prow(P2, 2, so); load_prow(P3, 3, so);
         transform_x_row(P0); transform_x_row(P1); transform_x_row(P2); transform_x_row(P3);
-        vrow(R0{}); vrow(R1{}); vrow(R2{});        // row 3 follows in slot 0 of the first step
+        split_row(R0{}); split_row(R1{}); split_row(R2{});
+        yrow(R3{});                                  // row 3 goes through the split in slots 0..2 of the first step
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }
@@ -244,20 +283,26 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
     unsigned rel_p[ITEMS], ra_p[16], ovo_p[4], rvo_p[4];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) rel_p[i] = park(rel[i]);
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr)smem;       // parked as absolute LDS addresses: no base add at the use
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ra_p[i] = park(ra[i]);
+    for (int i = 0; i < 16; ++i) ra_p[i] = park(lds_base + ra[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ovo_p[i] = park(ovo[i]); rvo_p[i] = park(rvo[i]); }
-    auto load_prow_p = [&](f32x4 (&P)[4], int dy, unsigned slot_off) __attribute__((always_inline)) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) P[x] = ldsr(unpark(ra_p[dy * 4 + x]) + slot_off);
-    };
 
     unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2 + s0) * HWR;     // plane zo of step s0
     unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2 + s0) * HWO;
     in_pl += (unsigned long long)s0 * HWI;
 
-    // one input plane: s = step index (input plane z = zb-1+s), PH = s mod 3; MODE as in conv16_wino_kernel
+    // One input plane: s = step index (input plane z = zb-1+s), PH = s mod 3; MODE as in conv16_wino_kernel.
+    // Slot q = row (py = q / 3, dz = 2 - q % 3): 12 MFMAs, each followed by at most a few single-issue instructions that run in
+    // its shadow (F: cvts, AccVGPR reads, LDS reads, DMA issue), then a block of packed adds / DOT ops (K).  Measured beside
+    // v_mfma_f32_16x16x32_bf16 (tools/ubench/mfma_bf16_valu.hip): two cvt / and / mov / accvgpr_read class ops per MFMA are free,
+    // a v_pk_add_f32 or v_dot2c next to an MFMA costs ~15 cycles of pipeline switch however many follow it, 4.1 - 4.5 each.
+    //   input side, V row r of plane s+1 (its pieces are dead after slot 3r + 2):
+    //     K(3r+2) yrow   F(3r+3) h   K(3r+3) Y -= h   F(3r+4) m   K(3r+4) Y -= m   F(3r+5) l        (r = 3 wraps into slots 0..2)
+    //     patch rows: P2 F(0), P0 F(1), x-transforms K(1) / K(2);  P1 F(4), K(4);  P3 F(9), K(10);  plane s+2 -> LDS: F(3)
+    //   output side, row r of the finished plane (its dz = 2 MFMAs ran in slot 3r): F(3r+2) AccVGPR reads, K(3r+2) A^T;
+    //     K(8) / K(11): epilogue of output rows 0 / 1 and the residual loads of the NEXT plane into the registers just consumed.
     auto step = [&](auto ph_tag, int s, auto mode_tag) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
@@ -267,71 +312,88 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
         constexpr int AF = PH;                                               // acc slot of the plane finished by dz = 2
         const bool zo_ok = s >= 2;                                           // the finished plane zo = zb - 2 + s exists
         const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok ? HWO : 0u);
-        // residual of the plane the NEXT step finishes (a full step of lead)
-        const bool zn_ok = s + 1 >= 2 && s + 1 < nsteps && has_res;
-        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zn_ok ? res_pl + HWR : (unsigned long long)res_n), zn_ok ? HWR : 0u);
+        // residual of the finished plane: requested in K(0) / K(3), eight slots ahead of its use.  (No load is left in flight across
+        // the step boundary: with VMEM loads pending at the loop back-edge the compiler's waitcnt pass can no longer tell them from the
+        // LDS-direct loads and put vmcnt(0) in front of the first patch read of every third step.)
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res ? HWR : 0u);
         res_pl += HWR; out_pl += HWO;
+        const bool in_ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc((const void*)(in_ok ? in_pl : (unsigned long long)in_n), in_ok ? HWI : 0u);
+        if (!FIN) in_pl += HWI;
         static_for<0, 12>([&](auto q_tag) __attribute__((always_inline)) {
             constexpr int q = decltype(q_tag)::value;
             constexpr int py = q / 3, dz = 2 - q % 3;
             constexpr int as = (PH + 2 - dz) % 3;
             constexpr bool active = mb_row_active(MODE, dz);
-            if constexpr (active) {
-                constexpr int qn = mb_next_slot(MODE, q) % 12;
-                const unsigned un = ua + ub_row_off(qn);
-                constexpr bool opens = dz == 0 || (MODE == MB_S1O && dz == 1);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    // 6 MFMAs of two points, alternating between them (a dependent MFMA is two issue slots away)
-#pragma unroll
-                    for (int tm = 0; tm < 3; ++tm)
-#pragma unroll
-                        for (int px = 2 * h; px < 2 * h + 2; ++px) {
-                            const int i = py * 4 + px;
-                            // a new output plane starts from 0, except point (1,1), which enters all four outputs with weight +1 and carries the bias
-                            const f32x4 c = (opens && tm == 0) ? ((py == 1 && px == 1) ? bias4 : zero4) : acc[as][i];
-                            acc[as][i] = mfma_bf16(tm == 2 ? A2[px] : A1[px], tm == 1 ? B2[i] : B1[i], c);
-                        }
-                    // the fragments of this half are dead: the same registers receive the next row's
-#pragma unroll
-                    for (int px = 2 * h; px < 2 * h + 2; ++px) {
-                        A1[px] = ldsu(un + (unsigned)(px * UB_ROW_BYTES));
+            constexpr int qn = mb_next_slot(MODE, q) % 12;
+            const unsigned un = ua + ub_row_off(qn);
+            constexpr bool opens = dz == 0 || (MODE == MB_S1O && dz == 1);
+            using RS = std::integral_constant<int, (q / 3 + 3) % 4>;        // V row in the split pipeline during this slot
+            using STG = std::integral_constant<int, q % 3>;                  // its stage
+            // ---- F(q): MFMA i, then what runs in its shadow
+            static_for<0, 12>([&](auto i_tag) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_tag)::value;
+                if constexpr (active && !(PCC_WB_PROBE & 16)) {
+                    // two halves of two points each, three MFMAs per point, alternating between the points of a half (a dependent MFMA
+                    // is two issue slots away); a new output plane starts from 0, except point (1,1), which enters all four outputs
+                    // with weight +1 and carries the bias
+                    constexpr int h = i / 6, tm = (i % 6) / 2, px = 2 * h + (i & 1);
+                    constexpr int k = py * 4 + px;
+                    const f32x4 c = (opens && tm == 0) ? ((py == 1 && px == 1) ? bias4 : zero4) : acc[as][k];
+                    acc[as][k] = mfma_bf16(tm == 2 ? A2[px] : A1[px], tm == 1 ? B2[k] : B1[k], c);
+                    // the fragments of a point are dead behind its third MFMA: the same registers receive the next row's
+                    // (A2 first: LDS reads return in order, so the wait in front of the point's first MFMA -- on A1 -- covers both)
+                    if constexpr (tm == 2 && !(PCC_WB_PROBE & 256)) {
                         A2[px] = ldsu(un + (unsigned)(px * UB_ROW_BYTES + 1024));
+                        A1[px] = ldsu(un + (unsigned)(px * UB_ROW_BYTES));
                     }
                 }
-            }
-            // ---- everything else.  V row r of the next plane is built right behind the last use of the current one (slot 3r + 2).
-            if (!FIN) {
-                if (q == 0) vrow(R3{});                                   // row 3 of THIS plane (patch rows of the previous step)
-                else if (q == 1) {
-                    const bool ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
-                    const __amdgpu_buffer_rsrc_t rp = make_rsrc((const void*)(ok ? in_pl : (unsigned long long)in_n), ok ? HWI : 0u);
-                    in_pl += HWI;
+                if constexpr (!FIN) {
+                    if constexpr (i < 8 && !(PCC_WB_PROBE & 32)) cvt_task(RS{}, STG{}, i_tag);
+                    if constexpr (q == 0 && i >= 8 && !(PCC_WB_PROBE & 512)) P2[i - 8] = lds_abs(unpark_lds(ra_p[2 * 4 + i - 8]) + slotN);
+                    if constexpr (q == 1 && i >= 8 && !(PCC_WB_PROBE & 512)) P0[i - 8] = lds_abs(unpark_lds(ra_p[0 * 4 + i - 8]) + slotN);
+                    if constexpr (q == 4 && i >= 8 && !(PCC_WB_PROBE & 512)) P1[i - 8] = lds_abs(unpark_lds(ra_p[1 * 4 + i - 8]) + slotN);
+                    if constexpr (q == 9 && i >= 8 && !(PCC_WB_PROBE & 512)) P3[i - 8] = lds_abs(unpark_lds(ra_p[3 * 4 + i - 8]) + slotN);
+                    if constexpr (q == 3 && i >= 6 && !(PCC_WB_PROBE & 2))
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(smem + slotW + (wave * 5 + i - 6) * 1024), 16, (int)unpark(rel_p[i - 6]), 0, 0, 0);
+                }
+                if constexpr (q % 3 == 2 && !(PCC_WB_PROBE & 64)) {
+                    // AccVGPR reads of row q / 3 of the finished plane: one per MFMA in gaps 0..7, two in gaps 8..11
+                    constexpr int r = q / 3;
+                    constexpr int e0 = i < 8 ? i : 8 + 2 * (i - 8), ne = i < 8 ? 1 : 2;
 #pragma unroll
-                    for (int it = 0; it < ITEMS; ++it)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + slotW + (wave * 5 + it) * 1024), 16, (int)unpark(rel_p[it]), 0, 0, 0);
-                    load_prow_p(P0, 0, slotN); load_prow_p(P2, 2, slotN);
-                } else if (q == 2) { transform_x_row(P0); transform_x_row(P2); }
-                else if (q == 3) { vrow(R0{}); load_prow_p(P1, 1, slotN); }
-                else if (q == 4) transform_x_row(P1);
-                else if (q == 6) vrow(R1{});
-                else if (q == 9) { vrow(R2{}); load_prow_p(P3, 3, slotN); }
-                else if (q == 10) transform_x_row(P3);
+                    for (int e = e0; e < e0 + ne; ++e)
+                        acc_read1(Mr[e], acc[AF][r * 4 + (e >> 2)][e & 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // ---- K(q)
+            if constexpr (!FIN) {
+                if constexpr (q % 3 == 0 && !(PCC_WB_PROBE & 8)) dot_block(RS{}, ST0{});
+                if constexpr (q % 3 == 1 && !(PCC_WB_PROBE & 8)) dot_block(RS{}, ST1{});
+                if constexpr (!(PCC_WB_PROBE & 128)) {
+                    if constexpr (q == 1) transform_x_row(P2);
+                    if constexpr (q == 2) { transform_x_row(P0); yrow(R0{}); }
+                    if constexpr (q == 4) transform_x_row(P1);
+                    if constexpr (q == 5) yrow(R1{});
+                    if constexpr (q == 8) yrow(R2{});
+                    if constexpr (q == 10) transform_x_row(P3);
+                    if constexpr (q == 11) yrow(R3{});
+                }
             }
-            if (q == 2 || q == 5 || q == 8 || q == 11) {
-                // A^T along x on row r of the finished plane (its dz = 2 MFMAs ran in slot 3r), accumulate A^T along y
-                const int r = q / 3;
-                const f32x4 m0 = acc_read(acc[AF][r * 4 + 0]), m1 = acc_read(acc[AF][r * 4 + 1]), m2 = acc_read(acc[AF][r * 4 + 2]), m3 = acc_read(acc[AF][r * 4 + 3]);
+            if constexpr (q % 3 == 2 && !(PCC_WB_PROBE & 64)) {
+                // A^T along x on row r of the finished plane, accumulate A^T along y
+                constexpr int r = q / 3;
+                const f32x4 m0 = {Mr[0], Mr[1], Mr[2], Mr[3]}, m1 = {Mr[4], Mr[5], Mr[6], Mr[7]}, m2 = {Mr[8], Mr[9], Mr[10], Mr[11]}, m3 = {Mr[12], Mr[13], Mr[14], Mr[15]};
                 const f32x4 r0 = add4(add4(m0, m1), m2), r1 = sub4(sub4(m1, m2), m3);
                 if (r == 0) { S[0][0] = r0; S[0][1] = r1; }
                 else if (r == 1) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = r0; S[1][1] = r1; }
                 else if (r == 2) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
                 else { S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
             }
-            if (q == 8 || q == 11) {
-                // epilogue of output row oy (complete after reduction row 2 resp. 3): ReLU, residual, clip, float4 stores; then the
-                // residual of the next plane into the registers just consumed
-                const int oy = q == 8 ? 0 : 1;
+            if constexpr ((q == 8 || q == 11) && !(PCC_WB_PROBE & (64 | 4))) {
+                // epilogue of output row oy (complete after reduction row 2 resp. 3): ReLU, residual, clip, float4 stores
+                constexpr int oy = q == 8 ? 0 : 1;
 #pragma unroll
                 for (int v = 2 * oy; v < 2 * oy + 2; ++v) {
                     f32x4 o = S[v >> 1][v & 1];
@@ -345,18 +407,20 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
                 }
 #pragma unroll
                 for (int v = 2 * oy; v < 2 * oy + 2; ++v) buf_store4(rout, ost[v], unpark(ovo_p[v]), 0);
+            }
+            if constexpr ((q == 0 || q == 3) && !(PCC_WB_PROBE & 4)) {
 #pragma unroll
-                for (int v = 2 * oy; v < 2 * oy + 2; ++v) resv[v] = buf_load4(rres, unpark(rvo_p[v]), 0);
+                for (int v = 2 * (q / 3); v < 2 * (q / 3) + 2; ++v) resv[v] = buf_load4(rres, unpark(rvo_p[v]), 0);
             }
             // gfx950: a buffer_store_dwordx4 reads its data registers late (conv16_wino_kernel): keep them unwritten for one more slot
-            if (q == 9) { asm volatile("" ::"v"(ost[0])); asm volatile("" ::"v"(ost[1])); }
-            if (q == 0) { asm volatile("" ::"v"(ost[2])); asm volatile("" ::"v"(ost[3])); }
+            if constexpr (q == 9) { asm volatile("" ::"v"(ost[0])); asm volatile("" ::"v"(ost[1])); }
+            if constexpr (q == 0) { asm volatile("" ::"v"(ost[2])); asm volatile("" ::"v"(ost[3])); }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // the LDS-direct loads of plane s+2 (slot 1) must have landed before the barrier publishes them; younger: 4 stores and 4
-        // residual loads (slots 8, 11)
-        if (!FIN) {
-            __builtin_amdgcn_s_waitcnt(0x0F78);      // vmcnt(8) expcnt(7) lgkmcnt(15)
+        // the LDS-direct loads of plane s+2 (F(3)) must have landed before the barrier publishes them; younger: the residual loads of
+        // K(3) and the 4 stores of K(8) / K(11)
+        if (!FIN && !(PCC_WB_PROBE & 1)) {
+            __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6) expcnt(7) lgkmcnt(15)
             __syncthreads();
         }
     };

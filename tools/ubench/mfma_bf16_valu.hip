@@ -9,7 +9,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef NOMFMA
+#define MFMA(ACC)
+#else
 #define MFMA(ACC) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(a), "v"(b))
+#endif
 enum { ADD = 0, PKADD, ACCRD, MOV, DS128, CVTPK, AND, PERM, DOT2C, LSHL, DS64, SPLIT_RN, SPLIT_DOT, SPLIT_TRUNC, FMA };
 
 template <int K, int MODE>
