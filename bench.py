@@ -37,6 +37,10 @@ CHUNK = 32            # blocks per pipeline chunk (one chunk per step; steps str
 PROFILE_STRIDE = 4    # every 4th launch of the dominant layer carries the two HIP events of the live roofline measurement
 FLOPS_PER_BLOCK = 31.086e9   # c3p @64^3, compress 16.562 + decompress 14.524 GFLOP
 PEAK_FP32_MFMA = 157.3       # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+PEAK_BF16_MFMA = 2500.0      # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16x16x32_bf16)
+PEAK_HBM = 8000.0            # GB/s
+# tools/host_budget.sh: cores per rank below which the 1-GPU rate drops by more than 3 %
+HOST_MIN_CORES_PER_RANK = 3        # 16/8: 6929, 6: 6831, 4: 6609, 3: 6776, 2: 5574, 1: 3207 blocks/s (profiles/r04_host_budget.log)
 # Synthetic weights (no trained checkpoints exist in the container): Glorot-uniform kernels scaled so that the
 # coded statistics resemble a trained codec at a high-rate point: ~4 % non-zero y symbols (~1.5-2 KB per
 # block), ~5-7 k decoded points per 64^3 block (input: ~5 k points, 2 % occupancy).
@@ -280,7 +284,10 @@ def main():
     torch.set_num_threads(max(1, min(torch.get_num_threads(), ops.usable_cores() // max(world, 1))))
 
     # host range-coder threads: share the node's cores between the ranks
-    coder_threads = args.coder_threads or max(8, ops.usable_cores() // max(world, 1))     # (cgroup-quota aware: a 16-CPU container that shows 256 cores gets throttled by 256 threads)
+    # (cgroup-quota aware: a 16-CPU container that shows 256 cores gets throttled by 256 threads; never more threads than the
+    # cores this rank owns: 8 ranks in a 16-core container get 2 each)
+    cores_per_rank = max(1, ops.usable_cores() // max(world, 1))
+    coder_threads = args.coder_threads or cores_per_rank
     model = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads, precision=args.precision)
     model.compress([1, 1, RES, RES, RES])
     w = synthetic_weights(model)
@@ -353,7 +360,7 @@ def main():
     if dist is not None:
         # what the driver cannot see from outside: that RCCL really spans `world` ranks on distinct devices, what each rank
         # did, and what the closing collectives cost
-        own = torch.tensor([elapsed, n_blocks, float(steady_ms or 0.0)], dtype=torch.float64, device=device)
+        own = torch.tensor([elapsed, n_blocks, float(steady_ms or 0.0), host_cores_busy], dtype=torch.float64, device=device)
         torch.cuda.synchronize(device)
         tc0 = time.perf_counter()
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -374,6 +381,8 @@ def main():
                  'per_rank_blocks_per_s': [float(r[1] / r[0]) for r in per_rank],
                  'per_rank_elapsed_s': [float(r[0]) for r in per_rank],
                  'per_rank_steady_ms_per_step': [float(r[2]) or None for r in per_rank],
+                 'host_cores_busy_per_rank': [round(float(r[3]), 2) for r in per_rank], 'host_cores_per_rank': cores_per_rank,
+                 'host_bound': bool(max(float(r[3]) for r in per_rank) >= 0.9 * cores_per_rank),
                  'final_collectives_ms': coll_ms,
                  'final_collectives': 'all_reduce(MAX) of the elapsed time + all_reduce(SUM) of (blocks, bytes, points); after the timed region'}
     else:
@@ -453,6 +462,8 @@ def main():
                                     'mid-network storage, fixed threshold idx 128, encode+decode (BASELINE.json configs[4])'),
                        'blocks_per_gpu_per_step': BATCH, 'pipeline_chunk': args.chunk, 'coder_threads_per_rank': coder_threads,
                        'host_cores_busy_per_rank': round(host_cores_busy, 2), 'host_cpu_quota_cores': ops.usable_cores(),
+                       'host_cores_per_rank': cores_per_rank, 'host_bound': bool(host_cores_busy >= 0.9 * cores_per_rank),
+                       'host_min_cores_per_rank_measured': HOST_MIN_CORES_PER_RANK,
                        'device_allocations_in_timed_region': dev_allocs,
                        'cpu_quota_throttled_periods_in_timed_region': None if thr0 is None else thr1 - thr0, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',

@@ -297,7 +297,10 @@ size_t pcc_focal_scratch_floats(void);
  * (src/utils/patch_gaussian_conditional.py:27-31; src/model_types.py:291-292,382-387,404-407),
  * which the reference also runs on the CPU (patch_gaussian_conditional.py:105-106).
  * Streams are independent (one per block and per string); they are coded on `n_threads` host
- * threads (0 = hardware concurrency).
+ * threads (0 = hardware concurrency).  The workers belong to the CALLING thread (one persistent pool per calling
+ * thread, joined when that thread exits): a host that codes from two threads at once -- the encoder of one chunk beside the
+ * decoder of another -- owns 2 x n_threads workers and has to size n_threads for that; call from long-lived threads
+ * (a short-lived caller pays thread creation and teardown per call sequence).
  *   data[s], index[s] : n[s] int32 symbols / CDF-row indices of stream s (host pointers);
  *   index[s] == NULL  : row = i % index_mod (EntropyBottleneck: per-channel tables);
  *   cdf               : (rows, cdf_stride) int32, row r valid for cdf_size[r] entries;

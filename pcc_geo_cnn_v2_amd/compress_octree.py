@@ -23,118 +23,153 @@ logging.basicConfig(level=logging.INFO,
 logger = logging.getLogger(__name__)
 
 
-def write_pcs(pcs, folder):
+def _dump_clouds(folder, clouds):
+    """--debug: one PLY per block under `folder` (0.ply, 1.ply, ...)."""
     from .utils import pc_io
     os.makedirs(folder, exist_ok=True)
-    for j, points in enumerate(pcs):
-        pc_io.write_df(os.path.join(folder, f'{j}.ply'), pc_io.pa_to_df(points))
+    for n, cloud in enumerate(clouds):
+        pc_io.write_df(os.path.join(folder, f'{n}.ply'), pc_io.pa_to_df(cloud))
 
 
-def compress(args):
-    import torch
-    from . import ops, sharding
+class _Cloud:
+    """One input file of the command line and the files its rate points go to (one per optimisation metric)."""
+    __slots__ = ('source', 'targets', 'decoded')
+
+    def __init__(self, source, targets, decoded):
+        self.source, self.targets, self.decoded = source, targets, decoded
+
+
+def _plan(args):
+    """Command-line contract of /root/reference/src/compress_octree.py:131-183 -> (clouds, with_normals).  Every input file owns
+    len(opt_metrics) consecutive entries of --output_files (and of --dec_files when given)."""
     from .model_configs import ModelConfigType
-    from .model_syntax import save_compressed_file
-    from .utils import pc_io
-    from .utils.octree_coding import partition_octree
     from .utils.pc_metric import validate_opt_metrics
-
-    assert args.resolution > 0, 'resolution must be positive'
-    assert args.data_format in ['channels_first', 'channels_last']
+    if args.resolution <= 0:
+        raise AssertionError('resolution must be positive')
+    if args.data_format not in ('channels_first', 'channels_last'):
+        raise AssertionError(f'unknown data_format {args.data_format}')
+    if args.model_config not in ModelConfigType.keys():
+        raise AssertionError(f'unknown model_config {args.model_config}: one of {list(ModelConfigType.keys())}')
     with_normals = args.input_normals is not None
     # the reference's own default '--opt_metrics d1_psnr' is not in avail_opt_metrics, so its CLI asserts unless the flag is
     # given (compress_octree.py:37,154).  psnr is monotone in mse (pc_metric.py:55), so '<g>_psnr' is taken as '<g>_mse' here
-    for k, m in enumerate(args.opt_metrics):
-        if m in ('d1_psnr', 'd2_psnr'):
-            args.opt_metrics[k] = m[:3] + 'mse'
-            logger.warning(f"--opt_metrics {m}: not an optimisation metric of the reference; using the equivalent {args.opt_metrics[k]}")
-    validate_opt_metrics(args.opt_metrics, with_normals=with_normals)
-    files_mult = 1
-    if len(args.opt_metrics) > 1:
-        files_mult *= len(args.opt_metrics)
-        assert files_mult * len(args.input_files) == len(args.output_files)
-        assert files_mult * len(args.input_normals) == len(args.output_files)
-    else:
-        assert files_mult * len(args.input_files) == len(args.output_files)
-    decode_files = args.dec_files is not None
-    if decode_files:
-        assert files_mult * len(args.input_files) == len(args.dec_files)
-    assert args.model_config in ModelConfigType.keys()
+    metrics = []
+    for name in args.opt_metrics:
+        if name in ('d1_psnr', 'd2_psnr'):
+            logger.warning(f"--opt_metrics {name}: not an optimisation metric of the reference; using the equivalent {name[:3]}mse")
+            name = name[:3] + 'mse'
+        metrics.append(name)
+    args.opt_metrics = metrics
+    validate_opt_metrics(metrics, with_normals=with_normals)
+    per_cloud = len(metrics) if len(metrics) > 1 else 1
+    n_in = len(args.input_files)
+    if len(args.output_files) != per_cloud * n_in:
+        raise AssertionError(f'{n_in} input file(s) x {per_cloud} metric(s) need {per_cloud * n_in} output files, got {len(args.output_files)}')
+    if per_cloud > 1 and len(args.input_normals or ()) * per_cloud != len(args.output_files):
+        raise AssertionError('several optimisation metrics need one normals file per input file')
+    if args.dec_files is not None and len(args.dec_files) != per_cloud * n_in:
+        raise AssertionError(f'--dec_files: expected {per_cloud * n_in} paths, got {len(args.dec_files)}')
+    clouds = []
+    for k, source in enumerate(args.input_files):
+        span = slice(k * per_cloud, (k + 1) * per_cloud)
+        targets = list(args.output_files[span])
+        if len(set(targets)) != len(targets):
+            raise AssertionError(f'{targets} should have no duplicates')
+        clouds.append(_Cloud(source, targets, None if args.dec_files is None else list(args.dec_files[span])))
+    return clouds, with_normals
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+
+def _join_process_group():
+    """-> (rank, world, local device index).  Under torch.distributed.run the blocks are sharded over the ranks."""
+    import torch
+    from . import sharding
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         import torch.distributed as dist
         # PCC_DIST_BACKEND=gloo + PCC_DIST_SAME_GPU=1: every rank on GPU 0 with host-side collectives -- lets a 1-GPU box run the
         # sharded path end to end (tests/test_cli_gpu.py); the default is one GPU per rank over RCCL
         if os.environ.get('PCC_DIST_SAME_GPU'):
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
+            local = 0
+        torch.cuda.set_device(local)
         if os.environ.get('PCC_DIST_BACKEND', 'nccl') == 'gloo':
             dist.init_process_group('gloo')
         else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     rank, world = sharding.world_info()
-    assert not (args.debug and world > 1), '--debug dumps every intermediate of every block: run it on one GPU'
-    sess = ops.get_context(torch.device('cuda', local_rank))  # replaces tf.Session (compress_octree.py:84)
+    return rank, world, local
 
-    p_min, p_max, dense_tensor_shape = pc_io.get_shape_data(args.resolution, args.data_format)
-    points = pc_io.load_points(args.input_files, batch_size=args.read_batch_size)
+
+def _block_grid(resolution, level, data_format):
+    """Octree geometry: the bounding box of the whole cloud and the dense shape of one leaf block."""
+    from .utils import pc_io
+    _, _, shape = pc_io.get_shape_data(resolution, data_format)
+    spatial = slice(1, 4) if data_format == 'channels_first' else slice(0, 3)
+    box = shape[spatial].copy()
+    shape[spatial] = shape[spatial] // (1 << level)
+    return box, shape
+
+
+def _write_rate_point(target, decoded_path, binstr, streams, info, args, blocks, debug_t_list):
+    """The files of one rate point: <target> (gzip'd container), <target>.enc.metric.json, optionally the decoded cloud and the
+    --debug dumps (/root/reference/src/compress_octree.py:109-125 lists them)."""
+    from .model_syntax import save_compressed_file
+    from .utils import pc_io
+    folder = os.path.dirname(target)
+    if folder:
+        os.makedirs(folder, exist_ok=True)
+    payload = save_compressed_file(binstr, streams, args.resolution, args.octree_level, strict=True)
+    with gzip.open(target, 'wb') as fh:
+        fh.write(payload)
+    with open(target + '.enc.metric.json', 'w') as fh:
+        json.dump({name: float(val) for name, val in info['metrics'].items()}, fh, sort_keys=True, indent=4)
+    if decoded_path is not None:
+        pc_io.write_df(decoded_path, pc_io.pa_to_df(info['blocks_full']))
+    if args.debug:
+        pc_io.write_df(target + '.enc.ply', pc_io.pa_to_df(info['blocks_full']))
+        _dump_clouds(target + '.ori.blocks', blocks)
+        _dump_clouds(target + '.enc.blocks', info['x_hat_list'])
+        _dump_clouds(target + '.enc.blocks.depart', info['blocks_depart'])
+        np.savez_compressed(target + '.enc.data.npz', data=np.array(streams, dtype=object), debug_t_list=np.array(debug_t_list, dtype=object))
+
+
+def compress(args):
+    import torch
+    from . import ops
+    from .model_configs import ModelConfigType
+    from .utils import pc_io
+    from .utils.octree_coding import partition_octree
+
+    clouds, with_normals = _plan(args)
+    rank, world, local = _join_process_group()
+    if args.debug and world > 1:
+        raise AssertionError('--debug dumps every intermediate of every block: run it on one GPU')
+    sess = ops.get_context(torch.device('cuda', local))        # what tf.Session is to the reference (compress_octree.py:84)
+
+    geometry = pc_io.load_points(args.input_files, batch_size=args.read_batch_size)
     if with_normals:
-        normals = [pc_io.load_normals(x) for x in args.input_normals]
-        points = [np.hstack((p, n)) for p, n in zip(points, normals)]
-
+        geometry = [np.hstack((xyz, pc_io.load_normals(path))) for xyz, path in zip(geometry, args.input_normals)]
+    box, block_shape = _block_grid(args.resolution, args.octree_level, args.data_format)
     logger.info('Performing octree partitioning')
-    bbox_min = [0, 0, 0]
-    if args.data_format == 'channels_first':
-        bbox_max = dense_tensor_shape[1:].copy()
-        dense_tensor_shape[1:] = dense_tensor_shape[1:] // (2 ** args.octree_level)
-    else:
-        bbox_max = dense_tensor_shape[:3].copy()
-        dense_tensor_shape[:3] = dense_tensor_shape[:3] // (2 ** args.octree_level)
-    blocks_list, binstr_list = zip(*[partition_octree(p, bbox_min, bbox_max, args.octree_level) for p in points])
-    n_total = sum(len(b) for b in blocks_list)
-    logger.info(f'Processing resolution {args.resolution} with octree level {args.octree_level} resulting in '
-                f'dense_tensor_shape {dense_tensor_shape} and {n_total} blocks')
+    partitions = [partition_octree(cloud, [0, 0, 0], box, args.octree_level) for cloud in geometry]
+    logger.info(f'Processing resolution {args.resolution} with octree level {args.octree_level} resulting in dense_tensor_shape '
+                f'{block_shape} and {sum(len(blocks) for blocks, _ in partitions)} blocks')
 
-    x_shape = np.concatenate(((1,), dense_tensor_shape))
     model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size, precision=args.precision)
-    model.compress(x_shape)
-    model.restore(args.checkpoint_dir)  # asserts 'Checkpoint ... was not found' like compress_octree.py:91
+    model.compress(np.concatenate(((1,), block_shape)))
+    model.restore(args.checkpoint_dir)      # asserts 'Checkpoint ... was not found' like compress_octree.py:91
 
-    for i in range(len(args.input_files)):
-        ori_file, cur_points, blocks, binstr = [x[i] for x in (args.input_files, points, blocks_list, binstr_list)]
-        cur_output_files = [args.output_files[i * files_mult + j] for j in range(files_mult)]
-        if decode_files:
-            cur_dec_files = [args.dec_files[i * files_mult + j] for j in range(files_mult)]
-        assert len(set(cur_output_files)) == len(cur_output_files), f'{cur_output_files} should have no duplicates'
-        logger.info(f'Starting {ori_file} to {", ".join(cur_output_files)} with {len(blocks)} blocks')
-        data_list, data, debug_t_list = model.compress_blocks(sess, blocks, binstr, cur_points, args.resolution,
-                                                              args.octree_level, with_normals=with_normals,
-                                                              opt_metrics=args.opt_metrics, max_deltas=args.max_deltas,
-                                                              fixed_threshold=args.fixed_threshold, debug=args.debug,
-                                                              need_points=decode_files or args.debug)
-        if rank != 0:
-            continue
-        assert len(data_list) == files_mult
-        for j in range(len(cur_output_files)):
-            of, cur_data_list, cur_data = [x[j] for x in (cur_output_files, data_list, data)]
-            if os.path.split(of)[0]:
-                os.makedirs(os.path.split(of)[0], exist_ok=True)
-            with gzip.open(of, 'wb') as f:
-                f.write(save_compressed_file(binstr, cur_data_list, args.resolution, args.octree_level, strict=True))
-            if decode_files:
-                pc_io.write_df(cur_dec_files[j], pc_io.pa_to_df(cur_data['blocks_full']))
-            with open(of + '.enc.metric.json', 'w') as f:
-                json.dump({k: float(v) for k, v in cur_data['metrics'].items()}, f, sort_keys=True, indent=4)
-            if args.debug:
-                pc_io.write_df(of + '.enc.ply', pc_io.pa_to_df(cur_data['blocks_full']))
-                write_pcs(blocks, of + '.ori.blocks')
-                write_pcs(cur_data['x_hat_list'], of + '.enc.blocks')
-                write_pcs(cur_data['blocks_depart'], of + '.enc.blocks.depart')
-                np.savez_compressed(of + '.enc.data.npz', data=np.array(cur_data_list, dtype=object),
-                                    debug_t_list=np.array(debug_t_list, dtype=object))
-        logger.info(f'Finished {ori_file} to {", ".join(cur_output_files)} with {len(blocks)} blocks')
+    want_points = clouds[0].decoded is not None or args.debug
+    for cloud, points, (blocks, binstr) in zip(clouds, geometry, partitions):
+        logger.info(f'Starting {cloud.source} to {", ".join(cloud.targets)} with {len(blocks)} blocks')
+        streams, infos, debug_t_list = model.compress_blocks(
+            sess, blocks, binstr, points, args.resolution, args.octree_level, with_normals=with_normals, opt_metrics=args.opt_metrics,
+            max_deltas=args.max_deltas, fixed_threshold=args.fixed_threshold, debug=args.debug, need_points=want_points)
+        if rank == 0:       # the other ranks only took part in the collectives
+            if len(streams) != len(cloud.targets):
+                raise AssertionError(f'{len(streams)} rate points for {len(cloud.targets)} output files')
+            for n, target in enumerate(cloud.targets):
+                _write_rate_point(target, None if cloud.decoded is None else cloud.decoded[n], binstr, streams[n], infos[n], args, blocks, debug_t_list)
+            logger.info(f'Finished {cloud.source} to {", ".join(cloud.targets)} with {len(blocks)} blocks')
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -173,4 +208,6 @@ def build_parser():
 
 
 if __name__ == '__main__':
+    from . import want_hw_queues
+    want_hw_queues()        # before torch (the HIP runtime) loads: compress() imports it
     compress(build_parser().parse_args())

@@ -112,4 +112,6 @@ def build_parser():
 
 
 if __name__ == '__main__':
+    from . import want_hw_queues
+    want_hw_queues()        # before torch (the HIP runtime) loads: decompress() imports it
     decompress(build_parser().parse_args())

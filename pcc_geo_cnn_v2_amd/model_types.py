@@ -110,9 +110,12 @@ class _Immediate:
         return self.fn()
 
 
-def _host_dtypes():
-    """(symbol dtype, CDF-row dtype) of the host staging buffers: int16 / uint8; PCC_WIDE_SYMBOLS=1 keeps int32 (A/B runs)."""
-    return (torch.int32, torch.int32) if os.environ.get('PCC_WIDE_SYMBOLS') else (torch.int16, torch.uint8)
+def _host_dtypes(levels=64):
+    """(symbol dtype, CDF-row dtype) of the host staging buffers: int16 / uint8 (uint8 rows cover scale tables of up to 256
+    levels; larger tables keep int32 rows); PCC_WIDE_SYMBOLS=1 keeps int32 for both (A/B runs)."""
+    if os.environ.get('PCC_WIDE_SYMBOLS'):
+        return torch.int32, torch.int32
+    return torch.int16, (torch.uint8 if levels <= 256 else torch.int32)
 
 
 class _Pinned:
@@ -208,7 +211,7 @@ class CompressionModel:
 
     def _staging(self, ctx, slot, B, y_dhw, z_dhw=None):
         """Per pipeline slot: the device + pinned staging buffers of one encode (ops.SymbolStaging), cached."""
-        sym_t, row_t = _host_dtypes()
+        sym_t, row_t = _host_dtypes(len(getattr(self, 'scale_table', ())) or 64)
         F = self.num_filters
         key = (ctx.device.index, slot, B, tuple(y_dhw), None if z_dhw is None else tuple(z_dhw), sym_t, self.data_format)
         cache = self.__dict__.setdefault('_stagings', {})
@@ -441,6 +444,10 @@ class CompressionModel:
         debug).  This is the unit that shards across GPUs (sharding.py)."""
         ctx = self._ctx(sess)
         dhw = self._spatial(self.x_shape)
+        if not fixed_threshold:
+            # once per call what the reference asserts per block (model_opt.py:22-24): unknown metric names, d2_* without normals
+            from .utils.pc_metric import validate_opt_metrics
+            validate_opt_metrics(opt_metrics, with_normals)
         strings_list, threshold_list, debug_t_list, x_hat_list = [], [], [], []
         opt_metrics_ret = metric_names(opt_metrics, max_deltas)
         half = len(self.thresholds) // 2
@@ -499,7 +506,7 @@ class CompressionModel:
                     xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)
                     # blocks go over in their own dtype: the worker computes exactly what the in-process call would
                     if on_gpu:
-                        jobs = [('tally', np.ascontiguousarray(chunk[j]), xh[j], self.thresholds, True) for j in range(len(chunk))]
+                        jobs = [('tally', np.ascontiguousarray(chunk[j]), xh[j], self.thresholds, with_normals) for j in range(len(chunk))]
                     else:
                         jobs = [('decide', np.ascontiguousarray(chunk[j]), xh[j], self.thresholds, resolution, with_normals,
                                  list(opt_metrics), list(max_deltas)) for j in range(len(chunk))]
@@ -966,7 +973,7 @@ class CompressionModelV2(CompressionModel):
         zpacked = self._symbols_to_device(ctx, self._range_decode(eb.table, [s[1] for s in strings], nz,
                                                                   None if rows is None else [rows] * B, mod, zsym_h), zsym_release)
         # the 64 scale rows leave in stream order, one byte each
-        row_t = _host_dtypes()[1]
+        row_t = _host_dtypes(len(self.scale_table))[1]
         cf = self.data_format == 'channels_first'
         idx_s = torch.empty(self._stream_shape(B, [v // 8 for v in dhw], F), dtype=row_t, device=ctx.device)
         codec = self._codec(ctx)

@@ -18,7 +18,7 @@ from scipy.spatial import cKDTree
 GROUPS = ('d1', 'd2')
 _OPT_STEMS = ('sum_AB', 'sum_BA', 'sum_max', 'sum_mean', 'mse_AB', 'mse_BA', 'mse')
 # psnr is not offered for optimisation: it is monotone in mse (pc_metric.py:55)
-avail_opt_metrics = [f'{g}_{stem}' for stem in _OPT_STEMS for g in GROUPS]
+avail_opt_metrics = [f'{g}_{stem}' for g in GROUPS for stem in _OPT_STEMS]      # the reference's order (pc_metric.py:57-58): --help and assertion texts print it
 
 # slots of a tally vector (float64[5]); additive over disjoint parts of B (B->A terms) and of A (A->B terms)
 N_B, D1_AB, D1_BA, D2_AB, D2_BA = range(5)

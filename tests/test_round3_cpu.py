@@ -107,7 +107,9 @@ def test_metric_building_blocks():
             acc[j], cnt[j] = n[to_a[j]], 1
     assert np.array_equal(pc_metric.transfer_normals(n, to_a, to_b), acc / cnt[:, None])
     # the opt-metric list and its validation
-    assert pc_metric.avail_opt_metrics[:4] == ['d1_sum_AB', 'd2_sum_AB', 'd1_sum_BA', 'd2_sum_BA'] and len(pc_metric.avail_opt_metrics) == 14
+    # (the reference's expression and therefore its order, /root/reference/src/utils/pc_metric.py:57-58: --help prints the list)
+    stems = ['sum_AB', 'sum_BA', 'sum_max', 'sum_mean', 'mse_AB', 'mse_BA', 'mse']
+    assert pc_metric.avail_opt_metrics == [f'd1_{m}' for m in stems] + [f'd2_{m}' for m in stems]
     pc_metric.validate_opt_metrics(['d1_mse', 'd2_mse'], with_normals=True)
     with pytest.raises(AssertionError, match='not available without normals'):
         pc_metric.validate_opt_metrics(['d2_mse'])
@@ -205,7 +207,8 @@ def test_range_coder_on_narrow_host_arrays():
 # ---------------------------------------------------------------- not a transcription of the reference's Python
 REF = '/root/reference/src'
 PAIRS = [('pcc_geo_cnn_v2_amd/utils/pc_metric.py', 'utils/pc_metric.py'), ('pcc_geo_cnn_v2_amd/model_opt.py', 'model_opt.py'),
-         ('pcc_geo_cnn_v2_amd/model_types.py', 'model_types.py'), ('pcc_geo_cnn_v2_amd/model_syntax.py', 'model_syntax.py')]
+         ('pcc_geo_cnn_v2_amd/model_types.py', 'model_types.py'), ('pcc_geo_cnn_v2_amd/model_syntax.py', 'model_syntax.py'),
+         ('pcc_geo_cnn_v2_amd/compress_octree.py', 'compress_octree.py')]      # (compress() was 0.55 of the reference's)
 # the interface itself (names + argument lists) is the contract and is not counted: bodies are compared
 WATCHED = {'compute_metrics', 'compute_optimal_thresholds', 'build_points_threshold', 'select_best_per_opt_metric',
            'load_compressed_file', 'save_compressed_file', 'assign_attr', 'validate_opt_metrics', 'sum_d1', 'sum_d2', 'd1_res'}
@@ -273,19 +276,24 @@ def test_usable_cores_respects_affinity_and_quota(monkeypatch, tmp_path):
     assert ops.usable_cores() == len(os.sched_getaffinity(0))
 
 
-def test_package_asks_for_eight_hardware_queues_before_the_runtime_loads():
-    """The copy streams need hardware queues of their own beside RCCL's streams: the package sets
-    GPU_MAX_HW_QUEUES unless the caller already did."""
+def test_entry_points_ask_for_eight_hardware_queues_and_the_import_leaves_the_environment_alone():
+    """The copy streams need hardware queues of their own beside RCCL's streams.  Importing the package
+    does not touch the host process' environment; the entry points call want_hw_queues() before torch loads, which
+    respects a value the caller set and reports when it comes too late."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = 'import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import pcc_geo_cnn_v2_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
-    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
-    assert out == '8'
-    code = 'import os; os.environ["GPU_MAX_HW_QUEUES"] = "5"; import pcc_geo_cnn_v2_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'
-    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
-    assert out == '5'
+
+    def run(code):
+        return subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
+    assert run('import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import pcc_geo_cnn_v2_amd; print(os.environ.get("GPU_MAX_HW_QUEUES"))') == 'None'
+    assert run('import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import pcc_geo_cnn_v2_amd as p; print(p.want_hw_queues(), os.environ["GPU_MAX_HW_QUEUES"])') == 'True 8'
+    assert run('import os; os.environ["GPU_MAX_HW_QUEUES"] = "5"; import pcc_geo_cnn_v2_amd as p; print(p.want_hw_queues(), os.environ["GPU_MAX_HW_QUEUES"])') == 'True 5'
+    assert run('import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import torch, pcc_geo_cnn_v2_amd as p; print(p.want_hw_queues(), os.environ.get("GPU_MAX_HW_QUEUES"))') == 'False None'
+    for cli in ('compress_octree', 'decompress_octree'):
+        src = open(os.path.join(root, 'pcc_geo_cnn_v2_amd', cli + '.py')).read()
+        assert 'want_hw_queues()' in src.split("if __name__ == '__main__':")[1]
 
 
 def test_bench_flop_model_reproduces_the_survey_and_the_kernel_row_counts():
