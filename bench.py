@@ -143,6 +143,30 @@ def synthetic_blocks(n, device, seed0):
     return out
 
 
+def kernel_source_sha1(path):
+    """git blob hash of a source file (what `git hash-object` prints): ties a profiled number to the code it was measured on."""
+    import hashlib
+    data = open(path, 'rb').read()
+    return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()
+
+
+def traffic_provenance():
+    """HBM bytes per launch of the dominant kernel as profiled (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes,
+    tools/profile_round.sh -> profiles/dominant_kernel_traffic.json), with the hash of the kernel source it was taken on and
+    whether the source changed since (tests/test_round4_cpu.py fails on a stale file)."""
+    prof = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
+    if not os.path.exists(prof):
+        return None
+    d = json.load(open(prof))
+    src = os.path.join(ROOT, 'pcc_geo_cnn_v2_amd', 'csrc', d.get('kernel_source', 'conv_wino.hip'))
+    now = kernel_source_sha1(src) if os.path.exists(src) else None
+    return {'file': 'profiles/dominant_kernel_traffic.json', 'kernel': d.get('kernel'), 'hbm_bytes_per_launch': d.get('hbm_bytes_per_launch'),
+            'traffic_over_algorithmic': d.get('traffic_over_algorithmic'), 'kernel_source': d.get('kernel_source'),
+            'kernel_source_sha1_at_measurement': d.get('kernel_source_sha1'), 'kernel_source_sha1_now': now,
+            'stale': d.get('kernel_source_sha1') != now,
+            'method': 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, on tools/bench_one.py (a separate profiled run, not this one)'}
+
+
 def throttled_periods():
     """Scheduler periods in which this container was paused for exceeding its CPU quota (cgroup v2 cpu.stat), or None."""
     try:
@@ -184,6 +208,10 @@ def cpu_baseline(model, w, blocks_np, budget_s=12.0):
             break
     return dict(value=n / el, unit='blocks/s', cores=torch.get_num_threads(), threads_used=torch.get_num_threads(), kind='port',
                 host_logical_cores=os.cpu_count(), cpu_quota_cores=ops.usable_cores(),
+                # the port follows the reference's encoder graph literally (model_types.py:383,387: it range-DECODES the strings it just
+                # wrote to obtain z_hat / y_hat); the GPU path takes them from the quantiser (identical by construction), so the CPU
+                # figure carries work the GPU figure legitimately does not
+                includes_encoder_side_decode=True,
                 note='cores = threads_used = oneDNN intra-op threads, calibrated on one block among the counts the container\'s CPU '
                      'quota allows (batch-1 convs stop scaling well below the core count); host_logical_cores = what the box shows',
                 sample=f'{n} c3p 64^3 blocks, batch 1 (model_types.py:192-198 loop), oracle/torch_oracle.py: '
@@ -393,7 +421,7 @@ def main():
     # driver's one `bench.py --gpus 1` run times it too.  A separate, labelled object: never the headline value.
     secondary = None
     if args.workload == 'configs1' and args.precision == 'fp32' and world == 1 and not args.no_secondary:
-        res2, batch2, steps2 = 128, 8, max(6, args.steps // 2)
+        res2, batch2, steps2 = 128, 8, max(40, args.steps // 2)      # >= 40 steps: pipeline fill and drain (two chunks) weigh 5 % at most
         m2 = ModelConfigType['c3p'].build(batch_size=batch2, coder_threads=coder_threads, precision='fp16')
         m2.compress([1, 1, res2, res2, res2])
         m2.set_weights(w)
@@ -431,13 +459,24 @@ def main():
         avg_ms = float(np.mean(kern_ms)) if kern_ms else float('nan')
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
         winograd = os.environ.get('PCC_NO_WINOGRAD') is None
+        split = winograd and os.environ.get('PCC_NO_SPLIT') is None      # 16-channel layers on the bf16 MFMA pipe (conv_wino_bf16.hip)
+        alg_bytes_launch = 3.0 * args.chunk * RES ** 3 * 16 * 4           # input + residual + output of the timed layer, fp32
         if winograd:
-            # conv_wino.hip: F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap); padding planes skipped
+            # F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap); padding planes skipped
             exec_flops = flops_launch * wino_exec_factor(16, RES, args.chunk, ctx.num_cu)
-            dom_kernel = 'conv16_wino_kernel<relu> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the decoder; layer 7 runs the same kernel: 4 launches per step)'
-            dom_note = ('achieved/frac = fp32 MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3) in x-y + direct z: 16/36 * 63.67/64 of '
-                        'the direct-convolution flops for a whole-volume slab) / HIP-event launch time / dense fp32 MFMA peak; algorithmic_* restate it in the '
-                        'direct-convolution flops of SURVEY.md 8d (what a direct kernel would have to sustain for the same time)')
+            if split:
+                dom_kernel = ('conv16_wino_bf16_kernel<relu> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the '
+                              'decoder; layer 7 runs the same kernel: 4 launches per step)')
+                dom_note = ('split-bf16 Winograd: every fp32 operand = three bf16 pieces, six product terms in three v_mfma_f32_16x16x32_bf16 per row (fp32 '
+                            'accumulate), error equal to the exact-fp32 MFMA kernel (tests/test_conv_gpu.py).  The matrix work is 2.7x shorter than on the fp32 '
+                            'pipe, so the launch is no longer MFMA-bound: the nearest hardware roof is HBM (achieved/frac = algorithmic bytes: input + residual '
+                            '+ output, / HIP-event launch time / 8 TB/s); what actually limits it is VALU issue of the operand split at one wave per SIMD '
+                            '(DESIGN.md 3.0c, profiles/r04_*).  `mfma` restates it against the matrix peaks; PCC_NO_SPLIT=1 gives the fp32 line')
+            else:
+                dom_kernel = 'conv16_wino_kernel<relu> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the decoder; layer 7 runs the same kernel: 4 launches per step)'
+                dom_note = ('achieved/frac = fp32 MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3) in x-y + direct z: 16/36 * 63.67/64 of '
+                            'the direct-convolution flops for a whole-volume slab) / HIP-event launch time / dense fp32 MFMA peak; algorithmic_* restate it in the '
+                            'direct-convolution flops of SURVEY.md 8d (what a direct kernel would have to sustain for the same time)')
         else:
             exec_flops = flops_launch
             dom_kernel = 'conv16_pers_kernel<2,4,2,20,2> (Conv3DTranspose 16->16 k3 s1 @64^3, 4 launches per step)'
@@ -446,11 +485,30 @@ def main():
         alg_step, exec_step = c3p_step_flops(RES, args.chunk, num_cu=ctx.num_cu, winograd=winograd)
         assert abs(alg_step / FLOPS_PER_BLOCK - 1) < 2e-3, (alg_step, FLOPS_PER_BLOCK)       # the layer walk reproduces SURVEY.md 8d
         alg_bytes16 = 3.0 * args.chunk * RES ** 3 * 16 * 2            # fp16 mode: in + residual + out of the timed layer, fp16
-        traffic, traffic_src = None, None
-        prof = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
-        if winograd and os.path.exists(prof):
-            traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
-            traffic_src = 'profiles/dominant_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; not re-measured in this run)'
+        # HBM traffic of the dominant kernel is a PMC measurement of a separate profiled run (profiles/, tools/profile_round.sh): it is
+        # reported as what it is -- `traffic` (this run) stays null
+        traffic_profiled = traffic_provenance()
+        if split:
+            dom_roofline = {'bound': 'hbm', 'kernel': dom_kernel, 'achieved': alg_bytes_launch / (avg_ms * 1e-3) / 1e9, 'peak': PEAK_HBM, 'unit': 'GB/s',
+                            'frac': alg_bytes_launch / (avg_ms * 1e-3) / 1e9 / PEAK_HBM, 'traffic': None, 'traffic_profiled': traffic_profiled,
+                            'algorithmic_bytes_per_launch': alg_bytes_launch, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms),
+                            'timed_launch_stride': PROFILE_STRIDE,
+                            'mfma': {'executed_bf16_flops_per_launch': 6.0 * exec_flops, 'executed_bf16_tflops': 6.0 * achieved_exec,
+                                     'frac_of_bf16_mfma_peak': 6.0 * achieved_exec / PEAK_BF16_MFMA,
+                                     'fp32_equivalent_flops_per_launch': exec_flops, 'fp32_equivalent_tflops': achieved_exec,
+                                     'fp32_equivalent_over_fp32_mfma_peak': achieved_exec / PEAK_FP32_MFMA,
+                                     'algorithmic_flops_per_launch': flops_launch, 'algorithmic_tflops': achieved,
+                                     'algorithmic_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA,
+                                     'note': 'three bf16 MFMAs of K = 32 replace four fp32 MFMAs of K = 4 per row: 6x the multiply-adds of the fp32 kernel, on a 16x faster pipe'},
+                            'note': dom_note}
+        else:
+            dom_roofline = {'bound': 'mfma', 'kernel': dom_kernel,
+                            'achieved': achieved_exec, 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s', 'frac': achieved_exec / PEAK_FP32_MFMA,
+                            'traffic': None, 'traffic_profiled': traffic_profiled if winograd else None, 'algorithmic_bytes_per_launch': alg_bytes_launch,
+                            'executed_flops_per_launch': exec_flops, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms), 'timed_launch_stride': PROFILE_STRIDE,
+                            'algorithmic_flops_per_launch': flops_launch, 'algorithmic_tflops': achieved,
+                            'algorithmic_speedup_vs_direct_roof': achieved / PEAK_FP32_MFMA,
+                            'note': dom_note}
         out = {
             'metric': 'voxel_blocks_64cubed_per_sec_encode_decode' if args.workload == 'configs1' else
                       'voxel_blocks_128cubed_per_sec_encode_decode_FP16_MODE_not_the_headline', 'value': value, 'unit': 'blocks/s',
@@ -467,6 +525,10 @@ def main():
                        'device_allocations_in_timed_region': dev_allocs,
                        'cpu_quota_throttled_periods_in_timed_region': None if thr0 is None else thr1 - thr0, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
+                       'mfma_operand_split': (('16-channel k3 stride-1 layers (6 launches per step): fp32 operands as 3 bf16 pieces (8+8+8 significand bits, '
+                                               'round-to-nearest residuals), terms hh hm mh hl mm lh in 3 x v_mfma_f32_16x16x32_bf16 per (z tap, Winograd point), fp32 '
+                                               'accumulate, fixed order (conv_wino_bf16.hip); 32- and 64-channel layers: exact fp32 MFMA (their 96 KB of split weights per '
+                                               'cin group do not fit LDS beside the tile ring)') if split and args.precision == 'fp32' else None),
                        'bytes_per_block': n_bytes / n_blocks, 'decoded_points_per_block': n_pts / n_blocks,
                        'conv_tflops_whole_step_algorithmic': value * FLOPS_PER_BLOCK / 1e12,
                        # direct-convolution flops / time / peak: the Winograd layers execute 2.1-2.2x fewer multiplies
@@ -483,13 +545,7 @@ def main():
                           'traffic': None, 'algorithmic_bytes_per_launch': alg_bytes16, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms),
                           'note': 'fp16 mode: the layer is HBM-bound (fp16 MFMA is 16x the fp32 rate); achieved = fp16 bytes of input + residual + '
                                   'output / HIP-event launch time; HBM3E peak 8 TB/s, ~6.3 TB/s achievable (MI355X_MICROARCH.md)'}
-                         if args.precision == 'fp16' else {'bound': 'mfma', 'kernel': dom_kernel,
-                         'achieved': achieved_exec, 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s', 'frac': achieved_exec / PEAK_FP32_MFMA,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': 3.0 * args.chunk * RES ** 3 * 16 * 4,
-                         'executed_flops_per_launch': exec_flops, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms), 'timed_launch_stride': PROFILE_STRIDE,
-                         'algorithmic_flops_per_launch': flops_launch, 'algorithmic_tflops': achieved,
-                         'algorithmic_speedup_vs_direct_roof': achieved / PEAK_FP32_MFMA,
-                         'note': dom_note}),
+                         if args.precision == 'fp16' else dom_roofline),
         }
         out['secondary'] = secondary
         out['multi_gpu'] = multi

@@ -285,6 +285,22 @@ int pcc_d1_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, int32_t 
                            const int32_t* block_of, int64_t npts, void* workspace, uint64_t* s_ab,
                            uint64_t* hsum, uint64_t* hcnt, int32_t* tcount, void* stream);
 
+/* The same search with the point-to-plane statistics (D2; src/utils/pc_metric.py:109-131: the reference's experiment optimises
+ * d1_mse AND d2_mse, src/ev_experiment.yml:47).  D2 needs WHICH point is nearest; where several are equally near the reference
+ * takes whatever scipy's KD-tree returns (pc_metric.py:114) -- here the rule is fixed: the candidate with the lowest (x, y, z)
+ * in lexicographic order (= lowest row-major voxel index).  A decoded point takes the mean normal of the original points that
+ * chose it, summed in ascending point order (pc_metric.py:16-18).  Additional arguments:
+ *   normals     : (npts,3) float32, normal of original point i (device)
+ *   block_start : (B+1,) int32 offsets of the blocks' points inside pts (points are grouped by block, ascending) (device)
+ *   workspace2  : pcc_d12_search_workspace_bytes(B,D,H,W,npts) bytes of device memory (beside `workspace` of the D1 call)
+ *   d2_ab, d2_ba: (B,256) float64 (device): d2_sum_AB / d2_sum_BA of threshold t, valid for t < tcount[b]
+ * No floating-point atomics: every sum has a fixed order, results are bit-reproducible.                                    */
+size_t pcc_d12_search_workspace_bytes(int32_t B, int32_t D, int32_t H, int32_t W, int64_t npts);
+int pcc_d12_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, int32_t D, int32_t H, int32_t W, const float* thr,
+                            int32_t nthr, int32_t clip, const int32_t* pts, const int32_t* block_of, const int32_t* block_start,
+                            int64_t npts, const float* normals, void* workspace, void* workspace2, uint64_t* s_ab, uint64_t* hsum,
+                            uint64_t* hcnt, int32_t* tcount, double* d2_ab, double* d2_ba, void* stream);
+
 /* ---- focal loss (src/utils/focal_loss.py:5-12) ------------------------------------------
  * Deterministic two-stage reduction (wavefront DPP/shuffle tree, fixed block order); result is a
  * single float32 written to out[0] (device).  `scratch` must hold pcc_focal_scratch_floats().   */

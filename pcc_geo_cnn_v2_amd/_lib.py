@@ -22,7 +22,7 @@ EXPORTS = [
     'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
     'pcc_symbols_tiles', 'pcc_symbols_pack', 'pcc_symbols_unpack',
     'pcc_range_encode_batch', 'pcc_range_decode_batch', 'pcc_range_encode_batch_n', 'pcc_range_decode_batch_n', 'pcc_pmf_to_quantized_cdf',
-    'pcc_d1_search_workspace_bytes', 'pcc_d1_threshold_stats', 'pcc_octree_bucket',
+    'pcc_d1_search_workspace_bytes', 'pcc_d1_threshold_stats', 'pcc_d12_search_workspace_bytes', 'pcc_d12_threshold_stats', 'pcc_octree_bucket',
     'pcc_network_num_layers', 'pcc_network_layer', 'pcc_weights_blob_floats', 'pcc_weights_pack', 'pcc_weights_upload',
     'pcc_network_workspace_bytes', 'pcc_network_out_dims', 'pcc_network_forward', 'pcc_network_forward_analysis',
     'pcc_network_forward_synthesis', 'pcc_network_forward_hyper_a', 'pcc_network_forward_hyper_s',
@@ -105,6 +105,9 @@ def lib():
     L.pcc_d1_search_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.pcc_d1_search_workspace_bytes.restype = sz
     L.pcc_d1_threshold_stats.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.pcc_d12_search_workspace_bytes.argtypes = [i32, i32, i32, i32, C.c_int64]
+    L.pcc_d12_search_workspace_bytes.restype = sz
+    L.pcc_d12_threshold_stats.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pcc_octree_bucket.argtypes = [vp, C.c_int64, i32, i32, i32, vp, vp]
     L.pcc_octree_bucket.restype = C.c_int64
     L.pcc_network_num_layers.argtypes = [i32, i32]

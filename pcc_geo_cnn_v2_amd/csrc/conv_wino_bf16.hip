@@ -118,7 +118,7 @@ __host__ __device__ constexpr int mb_first_slot(int mode) {
         if (mb_row_active(mode, 2 - n % 3)) return n;
     return 0;
 }
-__host__ __device__ constexpr unsigned ub_row_off(int q) { return (unsigned)((((2 - q % 3) * 4 + q / 3) * 4) * UB_ROW_BYTES); }   // (dz, py) row, px = 0
+__host__ __device__ constexpr unsigned ub_row_off(int q) { return (unsigned)(q * 4 * UB_ROW_BYTES); }       // the image is stored in slot order: row (py, dz) of slot q, px = 0
 
 template <bool RELU, bool CLIP>
 __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int nwg) {
@@ -453,7 +453,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
 
 using namespace pccwino;
 
-// ---- host: split-bf16 image of the Winograd-transformed weights.  Per (cin group, cout group): [dz][py][px][operand][lane][8 bf16]
+// ---- host: split-bf16 image of the Winograd-transformed weights.  Per (cin group, cout group): [slot q = 3 py + 2 - dz][px][operand][lane][8 bf16]
+//      (the order the kernel consumes it in: the first 48 KB are the rows of slots 0..5)
 //      operand 0 = [Uh c0..c3 | Um c0..c3], operand 1 = [Ul | Uh];  cin = 16 cig + 4 (lane >> 4) + c, cout = 16 cog + (lane & 15)
 static inline unsigned short bf16_rn_bits(float v) {
     unsigned b;
@@ -483,8 +484,9 @@ void pcc_wino_bf16_pack(int ngroups, const float* u_f32, float* out) {
                     const float r2 = r1 - bf16_bits_to_float(m[c]);         // exact
                     l[c] = bf16_rn_bits(r2);
                 }
-                unsigned short* a1 = o + ((((size_t)pair * 48 + row) * 2 + 0) * 64 + lane) * 8;
-                unsigned short* a2 = o + ((((size_t)pair * 48 + row) * 2 + 1) * 64 + lane) * 8;
+                const int dz = row / 16, py = (row / 4) % 4, px = row % 4, orow = (3 * py + 2 - dz) * 4 + px;
+                unsigned short* a1 = o + ((((size_t)pair * 48 + orow) * 2 + 0) * 64 + lane) * 8;
+                unsigned short* a2 = o + ((((size_t)pair * 48 + orow) * 2 + 1) * 64 + lane) * 8;
                 for (int c = 0; c < 4; ++c) { a1[c] = h[c]; a1[4 + c] = m[c]; a2[c] = l[c]; a2[4 + c] = h[c]; }
             }
 }

@@ -10,6 +10,8 @@
 // Squared Euclidean distance transforms are separable: a 1-D two-sweep pass along z, then min-plus passes
 // along y and x with early termination (a candidate at axis distance d cannot win once d^2 >= best).
 // The host turns these integers into the reference's d1_* metrics and applies its selection logic unchanged.
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 
 namespace {
@@ -233,6 +235,328 @@ PCC_API int pcc_d1_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, 
             hipLaunchKernelGGL(k_edt_points, dim3(pblocks, nt), dim3(256), 0, st, g1, tcount, TC, t0, pts, block_of,
                                (long long)npts, D, H, W, (unsigned long long*)s_ab);
         }
+    }
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}
+
+
+// =====================================================================================================================
+// D2 (point-to-plane) statistics on the GPU (round 4; src/utils/pc_metric.py:109-131 inside the search of src/model_opt.py:33-73).
+//
+// D2 needs WHICH point is nearest, not only how far it is: nearest-INDEX transforms replace the distance transforms.  Ties are
+// the rule on a voxel grid and the reference's own numbers depend on the pick of scipy's KD-tree (pc_metric.py:114), so the rule
+// here is stated and deterministic: among equidistant candidates the one with the LOWEST (x, y, z) in lexicographic order (= the
+// lowest row-major voxel index, the order of np.argwhere).  Per pass of the separable transform that is "smaller coordinate
+// wins a tie", which composes to the lexicographic rule.
+//   B -> A (once per block): full-grid index transform of A -> a*(v); e(v) = ((v - a*) . n[a*])^2 in fp64;
+//        D2_BA(t) = sum_{v : level(v) > t} e(v), one workgroup per (block, t), fixed summation order.
+//   A -> B (per threshold):  z and y passes on the grid, x pass at the points of A -> b*(a, t);  the decoded point b* gets the MEAN
+//        normal of the original points that chose it, summed in ascending point order like the reference's loop (pc_metric.py:16-18):
+//        one stable radix sort of the (block, t, b*) keys of a whole chunk of thresholds groups them;
+//        D2_AB(t) = sum_a ((a - b*) . mean_n(b*))^2, one workgroup per (block, t), fixed order.
+// No float atomics anywhere: the results are bit-reproducible.
+namespace {
+
+constexpr unsigned char kNo8 = 0xFF;
+constexpr unsigned short kNo16 = 0xFFFF;
+
+// nearest set voxel along z (level > t), ties -> the smaller z.  thread <-> (line (x,y), t); out: [b][tl][x][y][z] uint8
+__global__ void __launch_bounds__(256) k_ft_z(const unsigned char* __restrict__ lev, const int* __restrict__ tcount, int tmax, int t0,
+                                              int lines, int W, unsigned char* __restrict__ out) {
+    const int b = blockIdx.z, tl = blockIdx.y, t = t0 + tl;
+    if (t >= tcount[b]) return;
+    const int line = blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= lines) return;
+    const unsigned char* l = lev + ((size_t)b * lines + line) * W;
+    unsigned char* o = out + (((size_t)b * tmax + tl) * lines + line) * W;
+    int last = -1;
+    for (int z = 0; z < W; ++z) {
+        if (l[z] > t) last = z;
+        o[z] = last < 0 ? kNo8 : (unsigned char)last;
+    }
+    int nxt = -1;
+    for (int z = W - 1; z >= 0; --z) {
+        if (l[z] > t) nxt = z;
+        const int prev = o[z] == kNo8 ? -1 : (int)o[z];
+        if (nxt >= 0 && (prev < 0 || nxt - z < z - prev)) o[z] = (unsigned char)nxt;        // strictly nearer only: a tie keeps the smaller z
+    }
+}
+
+// y pass: (y*, z*) minimising (y - y')^2 + (z - z*(x, y', z))^2, ties -> the smaller y'.  thread <-> output voxel
+__global__ void __launch_bounds__(256) k_ft_y(const unsigned char* __restrict__ in, const int* __restrict__ tcount, int tmax, int t0,
+                                              size_t nvox, int H, int W, unsigned short* __restrict__ out) {
+    const int b = blockIdx.z, tl = blockIdx.y, t = t0 + tl;
+    if (t >= tcount[b]) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    const size_t base = ((size_t)b * tmax + tl) * nvox;
+    const int z = (int)(i % W), y = (int)((i / W) % H);
+    const unsigned char* c = in + base + i;
+    unsigned best = 0xFFFFFFFFu, by = 0, bz = 0;
+    if (c[0] != kNo8) { const int dz = z - c[0]; best = (unsigned)(dz * dz); by = (unsigned)y; bz = c[0]; }
+    for (int d = 1; d < H; ++d) {
+        const unsigned dd = (unsigned)(d * d);
+        if (dd > best) break;                               // (>: a candidate at dd == best can still tie with a smaller y')
+        if (y - d >= 0) {
+            const unsigned char zs = c[-(ptrdiff_t)d * W];
+            if (zs != kNo8) { const int dz = z - zs; const unsigned tot = dd + (unsigned)(dz * dz); if (tot <= best) { best = tot; by = (unsigned)(y - d); bz = zs; } }
+        }
+        if (y + d < H) {
+            const unsigned char zs = c[(ptrdiff_t)d * W];
+            if (zs != kNo8) { const int dz = z - zs; const unsigned tot = dd + (unsigned)(dz * dz); if (tot < best) { best = tot; by = (unsigned)(y + d); bz = zs; } }
+        }
+    }
+    out[base + i] = best == 0xFFFFFFFFu ? kNo16 : (unsigned short)((by << 8) | bz);
+}
+
+// x pass over the full grid (index transform of A): out = x* << 16 | y* << 8 | z*, 0xFFFFFFFF = empty block
+__global__ void __launch_bounds__(256) k_ft_x_full(const unsigned short* __restrict__ in, size_t nvox, int D, int H, int W,
+                                                   unsigned* __restrict__ out) {
+    const int b = blockIdx.z;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    const size_t hw = (size_t)H * W;
+    const int z = (int)(i % W), y = (int)((i / W) % H), x = (int)(i / hw);
+    const unsigned short* c = in + (size_t)b * nvox + i;
+    unsigned best = 0xFFFFFFFFu, arg = 0xFFFFFFFFu;
+    auto cand = [&](int xs, unsigned dd, bool tie_wins) {
+        const unsigned short e = c[((ptrdiff_t)xs - x) * (ptrdiff_t)hw];
+        if (e == kNo16) return;
+        const int dy = y - (e >> 8), dz = z - (e & 255);
+        const unsigned tot = dd + (unsigned)(dy * dy + dz * dz);
+        if (tot < best || (tie_wins && tot == best)) { best = tot; arg = ((unsigned)xs << 16) | e; }
+    };
+    cand(x, 0, false);
+    for (int d = 1; d < D; ++d) {
+        const unsigned dd = (unsigned)(d * d);
+        if (dd > best) break;
+        if (x - d >= 0) cand(x - d, dd, true);
+        if (x + d < D) cand(x + d, dd, false);
+    }
+    out[(size_t)b * nvox + i] = arg;
+}
+
+// point index of every occupied voxel (lowest index when a voxel holds several points)
+__global__ void __launch_bounds__(256) k_index_grid(const int* __restrict__ pts, const int* __restrict__ block_of, long long npts,
+                                                    int D, int H, int W, int* __restrict__ grid) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const int x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    if (x < 0 || x >= D || y < 0 || y >= H || z < 0 || z >= W) return;
+    atomicMin(&grid[(((size_t)block_of[i] * D + x) * H + y) * W + z], (int)i);
+}
+
+// e(v) = ((v - a*) . n[a*])^2 for the voxels that can be decoded at all (level >= 1)
+__global__ void __launch_bounds__(256) k_plane_err_ba(const unsigned char* __restrict__ lev, const unsigned* __restrict__ fta,
+                                                      const int* __restrict__ idxgrid, const float* __restrict__ normals,
+                                                      size_t nvox, int D, int H, int W, double* __restrict__ e) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    double val = 0.0;
+    const unsigned a = fta[(size_t)b * nvox + i];
+    if (lev[(size_t)b * nvox + i] && a != 0xFFFFFFFFu) {
+        const int xs = (int)(a >> 16), ys = (int)((a >> 8) & 255), zs = (int)(a & 255);
+        const size_t hw = (size_t)H * W;
+        const int z = (int)(i % W), y = (int)((i / W) % H), x = (int)(i / hw);
+        const int pi = idxgrid[(size_t)b * nvox + ((size_t)xs * H + ys) * W + zs];
+        const double proj = (double)(x - xs) * (double)normals[(size_t)pi * 3] + (double)(y - ys) * (double)normals[(size_t)pi * 3 + 1] +
+                            (double)(z - zs) * (double)normals[(size_t)pi * 3 + 2];
+        val = proj * proj;
+    }
+    e[(size_t)b * nvox + i] = val;
+}
+
+// fixed-order block reduction of one double per thread (256 threads)
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+// D2_BA[b][t] = sum of e over the voxels with level > t.  One workgroup per (t, block); thread k adds voxels k, k + 256, ... in order
+__global__ void __launch_bounds__(256) k_d2_ba(const unsigned char* __restrict__ lev, const double* __restrict__ e,
+                                               const int* __restrict__ tcount, size_t nvox, double* __restrict__ d2_ba) {
+    __shared__ double sh[256];
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (t >= tcount[b]) return;
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < nvox; i += 256)
+        if (lev[(size_t)b * nvox + i] > t) s += e[(size_t)b * nvox + i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) d2_ba[(size_t)b * kT + t] = s;
+}
+
+// x pass at the points of A: b*(a, t) (row-major voxel index) as the key (block, t, b*) of the grouping sort
+__global__ void __launch_bounds__(256) k_ft_points(const unsigned short* __restrict__ g, const int* __restrict__ tcount, int tmax, int t0,
+                                                   const int* __restrict__ pts, const int* __restrict__ block_of, long long npts,
+                                                   int D, int H, int W, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+    const int tl = blockIdx.y, t = t0 + tl;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long key = ~0ull;
+    if (i < npts) {
+        const int b = block_of[i];
+        if (t < tcount[b]) {
+            const int xa = pts[i * 3], ya = pts[i * 3 + 1], za = pts[i * 3 + 2];
+            const size_t hw = (size_t)H * W;
+            const unsigned short* c = g + ((size_t)b * tmax + tl) * D * hw + (size_t)ya * W + za;
+            unsigned best = 0xFFFFFFFFu, arg = 0;
+            auto cand = [&](int xs, unsigned dd, bool tie_wins) {
+                const unsigned short e = c[(size_t)xs * hw];
+                if (e == kNo16) return;
+                const int dy = ya - (e >> 8), dz = za - (e & 255);
+                const unsigned tot = dd + (unsigned)(dy * dy + dz * dz);
+                if (tot < best || (tie_wins && tot == best)) { best = tot; arg = (unsigned)(((size_t)xs * H + (e >> 8)) * W + (e & 255)); }
+            };
+            cand(xa, 0, false);
+            for (int d = 1; d < D; ++d) {
+                const unsigned dd = (unsigned)(d * d);
+                if (dd > best) break;
+                if (xa - d >= 0) cand(xa - d, dd, true);
+                if (xa + d < D) cand(xa + d, dd, false);
+            }
+            key = ((unsigned long long)b << 32) | ((unsigned long long)tl << 24) | arg;      // arg < 2^21 (128^3), tl < 64
+        }
+        keys[(size_t)tl * npts + i] = key;
+        vals[(size_t)tl * npts + i] = (unsigned)i;
+    }
+}
+
+// sorted (block, t, b*) groups: the head of a group sums the normals of its members in ascending point order (the stable sort kept
+// it), every member gets ((a - b*) . mean)^2 written at its own (t, point) slot
+__global__ void __launch_bounds__(256) k_group_plane_err(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                         size_t n, const int* __restrict__ pts, const float* __restrict__ normals,
+                                                         long long npts, int H, int W, double* __restrict__ err) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const unsigned long long key = keys[j];
+    if (key == ~0ull || (j > 0 && keys[j - 1] == key)) return;          // not a group head
+    double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
+    size_t end = j;
+    for (; end < n && keys[end] == key; ++end) {
+        const size_t pi = vals[end];
+        sx += (double)normals[pi * 3]; sy += (double)normals[pi * 3 + 1]; sz += (double)normals[pi * 3 + 2]; cnt += 1.0;
+    }
+    sx /= cnt; sy /= cnt; sz /= cnt;
+    const unsigned arg = (unsigned)(key & 0xFFFFFFu), tl = (unsigned)((key >> 24) & 0xFF);
+    const int zs = (int)(arg % (unsigned)W), ys = (int)((arg / (unsigned)W) % (unsigned)H), xs = (int)(arg / (unsigned)(W * H));
+    for (size_t m = j; m < end; ++m) {
+        const size_t pi = vals[m];
+        const double proj = (double)(pts[pi * 3] - xs) * sx + (double)(pts[pi * 3 + 1] - ys) * sy + (double)(pts[pi * 3 + 2] - zs) * sz;
+        err[(size_t)tl * npts + pi] = proj * proj;
+    }
+}
+
+// D2_AB[b][t0 + tl] = sum over the points of block b of err[tl][.], fixed order
+__global__ void __launch_bounds__(256) k_d2_ab(const double* __restrict__ err, const int* __restrict__ block_start, const int* __restrict__ tcount,
+                                               int t0, long long npts, double* __restrict__ d2_ab) {
+    __shared__ double sh[256];
+    const int tl = blockIdx.x, b = blockIdx.y, t = t0 + tl;
+    if (t >= tcount[b]) return;
+    double s = 0.0;
+    for (long long i = block_start[b] + threadIdx.x; i < block_start[b + 1]; i += 256) s += err[(size_t)tl * npts + i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) d2_ab[(size_t)b * kT + t] = s;
+}
+
+struct D2Layout {
+    size_t ftz, fty, fta, idx, e, keys0, keys1, vals0, vals1, err, sort_tmp, sort_tmp_bytes, total;
+    int TC;
+};
+D2Layout d2_layout(int32_t B, size_t nvox, int64_t npts) {
+    D2Layout l;
+    // thresholds resident at a time: 3 bytes per voxel of index grids, 32 bytes per point of sort / error buffers -> ~1 GiB
+    size_t tc = ((size_t)1 << 30) / ((size_t)B * nvox * 3 + (size_t)npts * 32 + 1);
+    l.TC = (int)(tc < 4 ? 4 : tc > 64 ? 64 : tc);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    l.ftz = o; o += al((size_t)B * l.TC * nvox);
+    l.fty = o; o += al((size_t)B * l.TC * nvox * 2);
+    l.fta = o; o += al((size_t)B * nvox * 4);
+    l.idx = o; o += al((size_t)B * nvox * 4);
+    l.e = o; o += al((size_t)B * nvox * 8);
+    const size_t pairs = (size_t)l.TC * (size_t)npts;
+    l.keys0 = o; o += al(pairs * 8);
+    l.keys1 = o; o += al(pairs * 8);
+    l.vals0 = o; o += al(pairs * 4);
+    l.vals1 = o; o += al(pairs * 4);
+    l.err = o; o += al(pairs * 8);
+    size_t tmp = 0;
+    hipcub::DeviceRadixSort::SortPairs((void*)nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const unsigned*)nullptr,
+                                       (unsigned*)nullptr, (int)(pairs ? pairs : 1), 0, 48, (hipStream_t)0);
+    l.sort_tmp_bytes = tmp;
+    l.sort_tmp = o; o += al(tmp + 256);
+    l.total = o + 4096;
+    return l;
+}
+
+}  // namespace
+
+PCC_API size_t pcc_d12_search_workspace_bytes(int32_t B, int32_t D, int32_t H, int32_t W, int64_t npts) {
+    return d2_layout(B, (size_t)D * H * W, npts).total;
+}
+
+// As pcc_d1_threshold_stats (same D1 outputs, computed by the same kernels), plus the D2 sums of every threshold:
+//   normals: (npts, 3) float32 (device), block_start: (B + 1,) int32 offsets of the blocks' points in pts (device),
+//   workspace: pcc_d1_search_workspace_bytes, workspace2: pcc_d12_search_workspace_bytes,
+//   d2_ab, d2_ba: (B, 256) float64 (device), entry [b][t] valid for t < tcount[b].
+PCC_API int pcc_d12_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, int32_t D, int32_t H, int32_t W, const float* thr,
+                                    int32_t nthr, int32_t clip, const int32_t* pts, const int32_t* block_of, const int32_t* block_start,
+                                    int64_t npts, const float* normals, void* workspace, void* workspace2, uint64_t* s_ab, uint64_t* hsum,
+                                    uint64_t* hcnt, int32_t* tcount, double* d2_ab, double* d2_ba, void* stream) {
+    PCC_REQUIRE(normals && block_start && workspace2 && d2_ab && d2_ba && pts && npts > 0, "pcc_d12_threshold_stats: NULL argument");
+    PCC_REQUIRE((size_t)npts * 64 < ((size_t)1 << 31), "pcc_d12_threshold_stats: too many points for one call");
+    // D1 part (and the levels / tcount the D2 part builds on): unchanged kernels
+    { const int rc = pcc_d1_threshold_stats(ctx, x_hat, B, D, H, W, thr, nthr, clip, pts, block_of, npts, workspace, s_ab, hsum, hcnt, tcount, stream);
+      if (rc != PCC_OK) return rc; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nvox = (size_t)D * H * W;
+    const D2Layout l = d2_layout(B, nvox, npts);
+    unsigned char* w2 = (unsigned char*)workspace2;
+    unsigned char* ftz = w2 + l.ftz;
+    unsigned short* fty = (unsigned short*)(w2 + l.fty);
+    unsigned* fta = (unsigned*)(w2 + l.fta);
+    int* idx = (int*)(w2 + l.idx);
+    double* e = (double*)(w2 + l.e);
+    unsigned long long *keys0 = (unsigned long long*)(w2 + l.keys0), *keys1 = (unsigned long long*)(w2 + l.keys1);
+    unsigned *vals0 = (unsigned*)(w2 + l.vals0), *vals1 = (unsigned*)(w2 + l.vals1);
+    double* err = (double*)(w2 + l.err);
+    // buffers of the D1 call that are still valid: levels and occupancy at the start of `workspace`, and its "one" counter
+    unsigned char* lev = (unsigned char*)workspace;
+    unsigned char* occ = lev + (size_t)B * nvox;
+    const int TC1 = chunk_thresholds(B, nvox);
+    int* one = (int*)((unsigned short*)(occ + (size_t)B * nvox) + (size_t)B * nvox * 2 + (size_t)B * TC1 * nvox * 2);
+    const int lines = D * H;
+    const unsigned vox_blocks = (unsigned)((nvox + 255) / 256);
+    const unsigned pblocks = (unsigned)((npts + 255) / 256);
+    PCC_CHECK_HIP(hipMemsetAsync(d2_ab, 0, (size_t)B * kT * 8, st));
+    PCC_CHECK_HIP(hipMemsetAsync(d2_ba, 0, (size_t)B * kT * 8, st));
+    // ---- B -> A: index transform of the original points (occupancy as a one-threshold level set), plane error per voxel
+    PCC_CHECK_HIP(hipMemsetAsync(idx, 0x7F, (size_t)B * nvox * 4, st));
+    hipLaunchKernelGGL(k_index_grid, dim3(pblocks), dim3(256), 0, st, pts, block_of, (long long)npts, D, H, W, idx);
+    hipLaunchKernelGGL(k_ft_z, dim3((lines + 255) / 256, 1, B), dim3(256), 0, st, occ, one, 1, 0, lines, W, ftz);
+    hipLaunchKernelGGL(k_ft_y, dim3(vox_blocks, 1, B), dim3(256), 0, st, ftz, one, 1, 0, nvox, H, W, fty);
+    hipLaunchKernelGGL(k_ft_x_full, dim3(vox_blocks, 1, B), dim3(256), 0, st, fty, nvox, D, H, W, fta);
+    hipLaunchKernelGGL(k_plane_err_ba, dim3(vox_blocks, B), dim3(256), 0, st, lev, fta, idx, normals, nvox, D, H, W, e);
+    hipLaunchKernelGGL(k_d2_ba, dim3(nthr, B), dim3(256), 0, st, lev, e, tcount, nvox, d2_ba);
+    // ---- A -> B per chunk of thresholds (the D1 sums of this direction came from the D1 call above)
+    for (int t0 = 0; t0 < nthr; t0 += l.TC) {
+        const int nt = nthr - t0 < l.TC ? nthr - t0 : l.TC;
+        const size_t pairs = (size_t)nt * (size_t)npts;
+        hipLaunchKernelGGL(k_ft_z, dim3((lines + 255) / 256, nt, B), dim3(256), 0, st, lev, tcount, l.TC, t0, lines, W, ftz);
+        hipLaunchKernelGGL(k_ft_y, dim3(vox_blocks, nt, B), dim3(256), 0, st, ftz, tcount, l.TC, t0, nvox, H, W, fty);
+        hipLaunchKernelGGL(k_ft_points, dim3(pblocks, nt), dim3(256), 0, st, fty, tcount, l.TC, t0, pts, block_of, (long long)npts, D, H, W,
+                           keys0, vals0);
+        size_t tmp = l.sort_tmp_bytes;
+        PCC_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs((void*)(w2 + l.sort_tmp), tmp, keys0, keys1, vals0, vals1, (int)pairs, 0, 48, st));
+        hipLaunchKernelGGL(k_group_plane_err, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, keys1, vals1, pairs, pts, normals,
+                           (long long)npts, H, W, err);
+        hipLaunchKernelGGL(k_d2_ab, dim3(nt, B), dim3(256), 0, st, err, block_start, tcount, t0, (long long)npts, d2_ab);
     }
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;

@@ -18,6 +18,8 @@ The comparisons `x_hat > t` are done in float32 like the reference under its pin
 """
 import logging
 
+import os
+
 import numpy as np
 from scipy.spatial import cKDTree
 
@@ -235,8 +237,15 @@ class HostSearchPool:
 
 
 def gpu_search_supported(opt_metrics, dhw):
-    """The GPU distance-transform search covers the d1_* metrics of grids up to 128^3, with or without normals in the input."""
-    return max(dhw) <= 128 and any(m.startswith('d1_') for m in opt_metrics)
+    """The GPU search (csrc/threshold_search.hip) covers grids up to 128^3: the d1_* metrics by exact distance transforms, the
+    d2_* metrics (round 4) by nearest-index transforms with a stated tie rule (d2_on_gpu)."""
+    return max(dhw) <= 128
+
+
+def d2_on_gpu():
+    """d2_* statistics come from the GPU unless PCC_D2_HOST=1 asks for the round-3 path (scipy KD-trees in a worker pool: the
+    reference's own tie pick, 30x slower; A/B runs and the tie analysis of tests/test_threshold_search_gpu.py)."""
+    return os.environ.get('PCC_D2_HOST') is None
 
 
 def d1_tallies_gpu(ctx, blocks, x_hat, thresholds):
@@ -260,14 +269,53 @@ def d1_tallies_gpu(ctx, blocks, x_hat, thresholds):
     return out
 
 
-def decide_from_tallies(blocks, d1, n_thresholds, resolution, opt_metrics, max_deltas, d2_stats=None):
+def d12_tallies_gpu(ctx, blocks, x_hat, thresholds):
+    """Per-block D1 AND D2 tallies on the GPU.  blocks: list of (n_i, 6) arrays, xyz + normals (the last three columns, as
+    model_types.get_normals_if takes them).  Returns [float64[T_i, 5]].  Ties between equidistant nearest neighbours go to the
+    lowest (x, y, z) -- the reference takes scipy's pick (pc_metric.py:114); D1 does not depend on the pick."""
+    import torch
+    from . import ops
+    xyz = np.ascontiguousarray(np.concatenate([np.asarray(b)[:, :3] for b in blocks]).astype(np.uint32).astype(np.int32))
+    nrm = np.ascontiguousarray(np.concatenate([np.asarray(b)[:, np.asarray(b).shape[1] - 3:] for b in blocks]).astype(np.float32))
+    sizes = np.array([len(b) for b in blocks], np.int64)
+    bof = np.repeat(np.arange(len(blocks), dtype=np.int32), sizes)
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    dev = ctx.device
+    thr = torch.from_numpy(np.asarray(thresholds).astype(np.float32)).to(dev)
+    s_ab, s_ba, n_b, tcount, d2_ab, d2_ba = ops.d12_threshold_stats(
+        ctx, x_hat, thr, torch.from_numpy(xyz).to(dev), torch.from_numpy(bof).to(dev), torch.from_numpy(start).to(dev),
+        torch.from_numpy(nrm).to(dev), clip=True)
+    out = []
+    for i in range(len(blocks)):
+        T = int(tcount[i])
+        t = np.zeros((T, 5), np.float64)
+        t[:, PM.N_B], t[:, PM.D1_AB], t[:, PM.D1_BA] = n_b[i][:T], s_ab[i][:T], s_ba[i][:T]
+        t[:, PM.D2_AB], t[:, PM.D2_BA] = d2_ab[i][:T], d2_ba[i][:T]
+        out.append(t)
+    return out
+
+
+def mean_point_tally(block, with_normals):
+    """Tally of the rounded mean point (the guard of model_opt.py:59-68) without a KD-tree: its nearest original point by a plain
+    argmin (lowest index on a tie, the rule of the GPU path)."""
+    blk = np.asarray(block)
+    if not with_normals:
+        return mean_point_d1_tally(blk)
+    a = blk[:, :3]
+    mean_point = np.round(np.mean(a, axis=0))[np.newaxis, :]
+    to_a = np.array([int(np.argmin(PM.squared_norms(a - mean_point)))], np.int64)
+    return PM.pair_tally(a, mean_point, np.zeros(len(a), np.int64), to_a, blk[:, blk.shape[1] - 3:])
+
+
+def decide_from_tallies(blocks, d1, n_thresholds, resolution, opt_metrics, max_deltas, d2_stats=None, gpu_d2=False):
     """Decisions of a chunk from the GPU's D1 tallies (d1_tallies_gpu), merged with the host pool's (tallies, mean_tally) per
     block when d2_* metrics are requested: their D2 slots go into the GPU's table; the D1 slots of both sources are the same
     integers, which is asserted.  Returns (names, [best thresholds per block])."""
-    validate_opt_metrics(opt_metrics, with_normals=d2_stats is not None)
+    validate_opt_metrics(opt_metrics, with_normals=d2_stats is not None or gpu_d2)
     names, best = metric_names(list(opt_metrics), list(max_deltas)), []
     for i, blk in enumerate(blocks):
-        tallies, mean_tally = d1[i], mean_point_d1_tally(blk)
+        # gpu_d2: the tallies of d12_tallies_gpu already hold their D2 slots; the guard point follows the same tie rule
+        tallies, mean_tally = d1[i], mean_point_tally(blk, gpu_d2)
         if d2_stats is not None:
             host_t, host_mean = d2_stats[i]
             assert len(host_t) == len(tallies), 'host and GPU disagree on the number of non-empty level sets'

@@ -27,7 +27,7 @@ from . import _lib as L
 from . import model_transforms as MT
 from . import ops
 from .entropy_models import EntropyBottleneck, GaussianConditional, scale_table
-from .model_opt import d1_tallies_gpu, decide_from_tallies, gpu_search_supported, metric_names
+from .model_opt import d1_tallies_gpu, d12_tallies_gpu, d2_on_gpu, decide_from_tallies, gpu_search_supported, metric_names
 from .model_transforms import TransformType
 from .utils.octree_coding import departition_octree
 from .utils.pc_metric import cloud_metrics_batch
@@ -461,7 +461,8 @@ class CompressionModel:
             n_m = len(max_deltas) * len(opt_metrics)
             host = [f.result() for f in item['futures']] if item['futures'] is not None else None
             if item['d1'] is not None:
-                opt_metrics_ret, best_all = decide_from_tallies(chunk_, item['d1'], len(self.thresholds), resolution, opt_metrics, max_deltas, host)
+                opt_metrics_ret, best_all = decide_from_tallies(chunk_, item['d1'], len(self.thresholds), resolution, opt_metrics, max_deltas, host,
+                                                                gpu_d2=item['gpu_d2'])
             else:
                 opt_metrics_ret, best_all = host[0][0], [bt for _, bt in host]
             # a block whose decode is empty at every threshold returns len(opt_metrics) entries (model_opt.py:35-36); with
@@ -500,9 +501,10 @@ class CompressionModel:
                 # table) a few chunks later, so the pool always holds several chunks' worth of blocks.
                 want_d2 = any(m.startswith('d2_') for m in opt_metrics)
                 on_gpu = gpu_search_supported(opt_metrics, dhw)
+                gpu_d2 = want_d2 and on_gpu and d2_on_gpu()          # round 4: nearest-index transforms, stated tie rule
                 strings = enc['finish']()
-                item = dict(chunk=chunk, x_hat=x_hat, futures=None, d1=None)
-                if want_d2 or not on_gpu:
+                item = dict(chunk=chunk, x_hat=x_hat, futures=None, d1=None, gpu_d2=gpu_d2)
+                if (want_d2 and not gpu_d2) or not on_gpu:
                     xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)
                     # blocks go over in their own dtype: the worker computes exactly what the in-process call would
                     if on_gpu:
@@ -515,7 +517,7 @@ class CompressionModel:
                     pool = self._search_pool(len(blocks))
                     item['futures'] = [pool.submit(job) for job in jobs]
                 if on_gpu:
-                    item['d1'] = d1_tallies_gpu(ctx, chunk, x_hat, self.thresholds)
+                    item['d1'] = (d12_tallies_gpu if gpu_d2 else d1_tallies_gpu)(ctx, chunk, x_hat, self.thresholds)
                 pending.append(item)
                 if len(pending) > SEARCH_LAG:
                     finalize_search(pending.pop(0))

@@ -564,6 +564,32 @@ def d1_threshold_stats(ctx, x_hat, thr, pts, block_of, clip=True):
     return s_ab.cpu().numpy(), s_ba, n_b, tcount.cpu().numpy()
 
 
+def d12_threshold_stats(ctx, x_hat, thr, pts, block_of, block_start, normals, clip=True):
+    """d1_threshold_stats plus the D2 sums of every threshold (include/pcc_geo.h: pcc_d12_threshold_stats).  normals (n,3) float32,
+    block_start (B+1,) int32 -- on the device.  Returns (s_ab, s_ba, n_b, tcount, d2_ab, d2_ba); d2_* float64 (B,256)."""
+    assert x_hat.dtype == torch.float32 and x_hat.is_contiguous() and x_hat.dim() == 4
+    assert pts.dtype == torch.int32 and pts.is_contiguous() and block_of.dtype == torch.int32 and block_of.is_contiguous()
+    assert normals.dtype == torch.float32 and normals.is_contiguous() and normals.shape == pts.shape
+    assert block_start.dtype == torch.int32 and block_start.is_contiguous() and thr.dtype == torch.float32 and thr.is_contiguous()
+    B, D, H, W = x_hat.shape
+    assert block_start.numel() == B + 1
+    dev = x_hat.device
+    ws = torch.empty((L.lib().pcc_d1_search_workspace_bytes(B, D, H, W),), dtype=torch.uint8, device=dev)
+    ws2 = torch.empty((L.lib().pcc_d12_search_workspace_bytes(B, D, H, W, pts.shape[0]),), dtype=torch.uint8, device=dev)
+    s_ab = torch.empty((B, 256), dtype=torch.int64, device=dev)
+    hsum, hcnt = torch.empty_like(s_ab), torch.empty_like(s_ab)
+    d2_ab = torch.empty((B, 256), dtype=torch.float64, device=dev)
+    d2_ba = torch.empty_like(d2_ab)
+    tcount = torch.empty((B,), dtype=torch.int32, device=dev)
+    L.check(L.lib().pcc_d12_threshold_stats(ctx.handle, _ptr(x_hat), B, D, H, W, _ptr(thr), thr.numel(), int(clip), _ptr(pts), _ptr(block_of),
+                                            _ptr(block_start), pts.shape[0], _ptr(normals), _ptr(ws), _ptr(ws2), _ptr(s_ab), _ptr(hsum), _ptr(hcnt),
+                                            _ptr(tcount), _ptr(d2_ab), _ptr(d2_ba), ctx.stream), 'pcc_d12_threshold_stats')
+    hs, hc = hsum.cpu().numpy(), hcnt.cpu().numpy()
+    s_ba = np.concatenate([np.cumsum(hs[:, ::-1], 1)[:, ::-1][:, 1:], np.zeros((B, 1), np.int64)], 1)
+    n_b = np.concatenate([np.cumsum(hc[:, ::-1], 1)[:, ::-1][:, 1:], np.zeros((B, 1), np.int64)], 1)
+    return s_ab.cpu().numpy(), s_ba, n_b, tcount.cpu().numpy(), d2_ab.cpu().numpy(), d2_ba.cpu().numpy()
+
+
 # ---------------------------------------------------------------------------------------------
 # host range coder
 # ---------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): rocprofv3 evidence for profiles/.  Usage: tools/profile_round.sh <tag>
 # No trace domain other than --kernel-trace is ever combined with --pmc (gpurun refuses that), counters in separate passes.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -22,6 +22,7 @@ pmc() {
   PCC_BENCH_IMPL=0 timeout 120 $CMD 2>&1 | grep -v amdgpu.ids > $OUT/$KEY/time.log
 }
 pmc wino16 32 64 16 16 3 1 1 res
+export PCC_NO_SPLIT=1; pmc wino16_fp32 32 64 16 16 3 1 1 res; unset PCC_NO_SPLIT
 pmc cin32 32 32 32 32 3 1 1 res
 pmc cin64 32 16 64 64 3 1 1 res
 pmc tr2m 32 32 32 16 3 2 1

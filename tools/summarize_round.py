@@ -13,8 +13,10 @@ PEAK_TF, HBM_TBS = 157.3, 8.0
 B = 32
 # key -> (kernel name fragment, description, algorithmic flops per launch, executed-MFMA flops per launch (None = counter), algorithmic bytes, bound)
 KERNELS = {
-    'wino16': ('conv16_wino_kernel', 'Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32 (Winograd F(2x2,3x3) x-y + direct z)',
-               2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'mfma'),
+    'wino16': ('conv16_wino_bf16_kernel', 'Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32 (split-bf16 Winograd F(2x2,3x3) x-y + direct z, conv_wino_bf16.hip)',
+               2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'hbm'),
+    'wino16_fp32': ('conv16_wino_kernel', 'the same layer on the exact-fp32 MFMA Winograd kernel (PCC_NO_SPLIT=1, conv_wino.hip): the A/B line of the split path',
+                    2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'mfma'),
     'cin32': ('conv16_wino_cin_kernel<true, 2>', 'Conv3DTranspose 32->32 k3 s1 @32^3 + residual, batch 32 (Winograd, cin groups inside the z march)',
               2.0 * B * 32 ** 3 * 27 * 32 * 32, B * 32 ** 3 * 32 * 4 * 3, 'mfma'),
     'cin64': ('conv16_wino_cin_kernel<true, 4>', 'Conv3DTranspose 64->64 k3 s1 @16^3 + residual, batch 32 (Winograd, cin groups inside the z march, U streamed)',
@@ -48,6 +50,8 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
     fetch = pmc.get('FETCH_SIZE', float('nan')) * 1024 * 2      # KB -> B, x2: gfx950 FETCH_SIZE counts 64 B per 128 B request (MI355X_MICROARCH.md)
     write = pmc.get('WRITE_SIZE', float('nan')) * 1024
     exec_flops = pmc.get('SQ_INSTS_VALU_MFMA_MOPS_F32', float('nan')) * 512
+    if key == 'wino16':     # bf16 MFMAs: v_mfma_f32_16x16x32_bf16 = 16384 flops each (SQ_INSTS_MFMA counts instructions per wave)
+        exec_flops = pmc.get('SQ_INSTS_MFMA', float('nan')) * 16384
     simd_cycles = pmc.get('GRBM_GUI_ACTIVE', float('nan')) / 8 * 1024
     out = {'key': key, 'kernel': frag, 'layer': desc, 'bound': bound,
            'launch_us_unprofiled_min': t_min, 'launch_us_unprofiled_median': t_med,
@@ -67,7 +71,11 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
            'raw_counters': pmc}
     rows.append(out)
     if key == 'wino16':
-        traffic_json = dict(out, method='rocprofv3 --pmc, one pass per counter group, on tools/bench_one.py 32 64 16 16 3 1 1 res; FETCH_SIZE doubled per '
+        import hashlib
+        ksrc = 'conv_wino_bf16.hip'
+        data = open(os.path.join(root, 'pcc_geo_cnn_v2_amd', 'csrc', ksrc), 'rb').read()
+        out['executed_frac_of_bf16_mfma_peak'] = out['executed_tflops'] / 2500.0
+        traffic_json = dict(out, kernel_source=ksrc, kernel_source_sha1=hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest(), method='rocprofv3 --pmc, one pass per counter group, on tools/bench_one.py 32 64 16 16 3 1 1 res; FETCH_SIZE doubled per '
                             'MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B fabric request); WRITE_SIZE as reported (uncalibrated)')
 json.dump(traffic_json, open(os.path.join(dst, 'dominant_kernel_traffic.json'), 'w'), indent=1)
 json.dump(rows, open(os.path.join(dst, f'{tag}_kernel_counters.json'), 'w'), indent=1)
