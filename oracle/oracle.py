@@ -436,3 +436,52 @@ def decompress_block(model, strings, x_shape, run=None, indexes=None):
     x_hat = np.asarray(run(cfg['s'], F, P, 'synthesis', y_hat), np.float32)
     dbg.update(y_hat=y_hat, x_hat=x_hat)
     return x_hat[0, :, :, :, 0], dbg
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# D1 / D2 statistics of the adaptive threshold search with a STATED tie rule (round 4)
+# ---------------------------------------------------------------------------------------------------------------------
+def search_tallies_lowest_index(block, x_hat, thresholds):
+    """Brute-force restatement of the per-threshold statistics of /root/reference/src/model_opt.py:33-56 with
+    /root/reference/src/utils/pc_metric.py:76-131, for one block: rows (|B_t|, d1_sum_AB, d1_sum_BA, d2_sum_AB, d2_sum_BA) of
+    the leading non-empty level sets B_t = argwhere(clip(x_hat) > thr[t]).  Where the reference takes whatever neighbour
+    scipy's KD-tree returns among equidistant ones (pc_metric.py:114), this restatement -- like csrc/threshold_search.hip -- takes
+    the one with the lowest (x, y, z) in lexicographic order.  block: (n, 6) = xyz + normals.  O(n |B_t|) memory: small cases."""
+    a = np.asarray(block)[:, :3].astype(np.float64)
+    n_a = np.asarray(block)[:, 3:6].astype(np.float32).astype(np.float64)       # (float32 normals, promoted like the product path)
+    xh = np.clip(np.asarray(x_hat, np.float32), 0.0, 1.0)
+    a_order = np.lexsort((a[:, 2], a[:, 1], a[:, 0]))                          # original points in (x, y, z) order
+    rows = []
+    for t in thresholds:
+        b = np.argwhere(xh > np.float32(t)).astype(np.float64)                 # lexicographic (x, y, z) order
+        if len(b) == 0:
+            break
+        d = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)                     # exact integers in float64
+        to_b = d.argmin(axis=1)                                                # first minimum = lowest (x, y, z)
+        to_a = a_order[d[a_order].argmin(axis=0)]
+        cnt = np.bincount(to_b, minlength=len(b)).astype(np.float64)
+        acc = np.zeros((len(b), 3))
+        np.add.at(acc, to_b, n_a)                                              # ascending point order, like pc_metric.py:16-18
+        orphan = cnt == 0
+        acc[orphan] = n_a[to_a[orphan]]
+        cnt[orphan] = 1
+        n_b = acc / cnt[:, None]
+        gap_ab, gap_ba = a - b[to_b], b - a[to_a]
+        rows.append((len(b), d.min(axis=1).sum(), d.min(axis=0).sum(),
+                     (((gap_ab * n_b[to_b]).sum(1)) ** 2).sum(), (((gap_ba * n_a[to_a]).sum(1)) ** 2).sum()))
+    return np.array(rows, np.float64).reshape(-1, 5)
+
+
+def tie_free(block, x_hat, thresholds):
+    """Per leading non-empty level set: True when every original point has ONE nearest decoded point and every decoded point ONE
+    nearest original point -- the only case in which the reference's D2 (pc_metric.py:109-131) is defined without a tie rule."""
+    a = np.asarray(block)[:, :3].astype(np.float64)
+    xh = np.clip(np.asarray(x_hat, np.float32), 0.0, 1.0)
+    out = []
+    for t in thresholds:
+        b = np.argwhere(xh > np.float32(t)).astype(np.float64)
+        if len(b) == 0:
+            break
+        d = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        out.append(bool(((d == d.min(axis=1, keepdims=True)).sum(axis=1) == 1).all() and ((d == d.min(axis=0, keepdims=True)).sum(axis=0) == 1).all()))
+    return out

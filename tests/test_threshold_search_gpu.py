@@ -104,3 +104,99 @@ def test_fortran_ordered_blocks(ctx):
         hn, hb = model_opt.compute_optimal_thresholds(np.ascontiguousarray(b), np.clip(xh, 0, 1), thresholds, 64,
                                                       opt_metrics=['d1_mse', 'd1_sum_mean'], max_deltas=[np.inf, 1.5])
         assert hn == names and hb == bt
+
+
+# ------------------------------------------------------------------------------------------------------------ D2 on the GPU (round 4)
+def _case6(rng, R, npts, sharp):
+    block, x_hat = _case(rng, R, npts, sharp)
+    nrm = rng.standard_normal((len(block), 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return np.hstack([block, nrm.astype(np.float32)]), x_hat
+
+
+@pytest.mark.parametrize('R', [16, 32])
+def test_d2_stats_match_the_lowest_index_restatement(ctx, oracle, R):
+    """pcc_d12_threshold_stats against the brute-force restatement with the same stated tie rule (oracle.search_tallies_lowest_index):
+    |B_t| and the D1 sums exactly, the D2 sums to 1e-11 (fp64 sums in another order); twice -> bit-identical."""
+    rng = np.random.default_rng(100 + R)
+    thresholds = np.linspace(0, 1.0, 256)
+    blocks, xs = zip(*[_case6(rng, R, n, s) for n, s in [(40, 0.7), (300, 1.0), (3, 0.5), (700, 1.4)]])
+    x_hat = torch.from_numpy(np.stack(xs)).to(ctx.device)
+    got = model_opt.d12_tallies_gpu(ctx, list(blocks), x_hat, thresholds)
+    again = model_opt.d12_tallies_gpu(ctx, list(blocks), x_hat, thresholds)
+    d1 = model_opt.d1_tallies_gpu(ctx, list(blocks), x_hat, thresholds)
+    for i, (blk, xh) in enumerate(zip(blocks, xs)):
+        ref = oracle.search_tallies_lowest_index(blk, xh, thresholds)
+        assert got[i].shape == ref.shape and len(ref) > 3
+        assert np.array_equal(got[i][:, :3], ref[:, :3]) and np.array_equal(got[i][:, :3], d1[i][:, :3])
+        assert np.allclose(got[i][:, 3:], ref[:, 3:], rtol=1e-11, atol=1e-300), (i, np.abs(got[i][:, 3:] / ref[:, 3:] - 1).max())
+        assert np.array_equal(got[i], again[i])
+
+
+def test_d2_search_against_the_reference_fixtures_and_tie_free_cases(ctx, oracle):
+    """(a) tests/golden/model_opt_d2.npz (the reference's own metric dictionaries and decisions, scipy's tie pick; resolution 64):
+    every d1_* number of the GPU path equals the reference's; its level sets all contain equidistant neighbours (voxel grids), so the
+    d2_* numbers and decisions may differ there -- only there: (b) on random sparse cases WITHOUT ties the GPU tallies equal the
+    KD-tree path's (model_opt.host_threshold_stats, the restatement those fixtures pin) to 1e-11."""
+    from pcc_geo_cnn_v2_amd.utils import pc_metric as PM
+    g = np.load(os.path.join(G, 'model_opt_d2.npz'), allow_pickle=True)
+    thresholds = np.linspace(0, 1.0, 256)
+    mets, deltas = [str(m) for m in g['opt_metrics']], [float(d) for d in g['max_deltas']]
+    for i in range(int(g['n_cases'][0])):
+        blk, xh = g[f's{i}_block'], g[f's{i}_x_hat']
+        tallies = model_opt.d12_tallies_gpu(ctx, [blk], torch.from_numpy(xh[None]).to(ctx.device), thresholds)[0]
+        free = oracle.tie_free(blk, xh, thresholds)
+        for t in (40, 100, 160):
+            if t >= len(tallies):
+                continue
+            table = PM.metrics_table(len(blk), tallies[t], 63)
+            ref = dict(zip([str(k) for k in g[f's{i}_t{t}_keys']], g[f's{i}_t{t}_vals']))
+            for k, v in ref.items():
+                if k.startswith('d1_') or free[t]:
+                    assert np.isclose(table[k], v, rtol=1e-6), (i, t, k, table[k], v)      # (case 2 is a float32 block: the reference rounds there)
+        names, best = model_opt.decide_from_tallies([blk], [tallies], len(thresholds), 64, mets, deltas, gpu_d2=True)
+        assert names == [str(n) for n in g[f's{i}_names']]
+        for k, (mine, theirs) in enumerate(zip(best[0], [int(b) for b in g[f's{i}_best']])):
+            assert mine == theirs or (names[k].startswith('d2_') and not all(free)), (i, names[k], mine, theirs)
+    # (b) tie-free cases: a handful of scattered points against a handful of scattered decoded voxels
+    rng = np.random.default_rng(2024)
+    R, kept = 16, 0
+    for trial in range(400):
+        a = np.unique(rng.integers(0, R, (int(rng.integers(2, 7)), 3)), axis=0).astype(np.float64)
+        nr = rng.standard_normal((len(a), 3)).astype(np.float32)
+        xh = np.zeros((R, R, R), np.float32)
+        vox = np.unique(rng.integers(0, R, (int(rng.integers(2, 7)), 3)), axis=0)
+        xh[tuple(vox.T)] = rng.uniform(0.05, 0.95, len(vox)).astype(np.float32)
+        blk = np.hstack([a, nr])
+        free = oracle.tie_free(blk, xh, thresholds)
+        if not all(free):
+            continue
+        kept += 1
+        got = model_opt.d12_tallies_gpu(ctx, [blk], torch.from_numpy(xh[None]).to(ctx.device), thresholds)[0]
+        host, _ = model_opt.host_threshold_stats(blk, np.clip(xh, 0, 1), thresholds, normals=blk[:, 3:6])
+        assert got.shape == host.shape and np.array_equal(got[:, :3], host[:, :3])
+        assert np.allclose(got[:, 3:], host[:, 3:], rtol=1e-11, atol=1e-300), (trial, got[:, 3:], host[:, 3:])
+    assert kept >= 20, kept
+
+
+def test_adaptive_encode_with_d2_metrics_issues_no_host_job(ctx, monkeypatch):
+    """compress_blocks with ['d1_mse', 'd2_mse'] and normals (the reference's experiment, src/ev_experiment.yml:47): everything on
+    the GPU (no worker-pool job); PCC_D2_HOST=1 restores the KD-tree pool, whose decisions may differ only through ties."""
+    from pcc_geo_cnn_v2_amd.model_configs import ModelConfigType
+    from pcc_geo_cnn_v2_amd import init_checkpoint
+    rng = np.random.default_rng(5)
+    model = ModelConfigType['c3p'].build(batch_size=4)
+    model.compress([1, 1, 32, 32, 32])
+    model.set_weights(init_checkpoint.make_synthetic_weights('c3p', seed=3, final_bias=0.3))
+    blocks = []
+    for n in (500, 900, 200):
+        b = np.unique(rng.integers(4, 28, (n, 3)), axis=0).astype(np.float64)
+        nr = rng.standard_normal((len(b), 3)); nr /= np.linalg.norm(nr, axis=1, keepdims=True)
+        blocks.append(np.hstack([b, nr]))
+    model.host_search_jobs = 0
+    out = model.encode_block_range(ctx, blocks, 32, with_normals=True, opt_metrics=['d1_mse', 'd2_mse'], max_deltas=[np.inf])
+    assert model.host_search_jobs == 0 and out[3] == ['d1_mse_inf', 'd2_mse_inf']
+    monkeypatch.setenv('PCC_D2_HOST', '1')
+    host = model.encode_block_range(ctx, blocks, 32, with_normals=True, opt_metrics=['d1_mse', 'd2_mse'], max_deltas=[np.inf])
+    assert model.host_search_jobs == len(blocks)
+    assert out[0] == host[0] and [t[0] for t in out[1]] == [t[0] for t in host[1]]          # strings and the d1 decisions are the same

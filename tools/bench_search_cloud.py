@@ -1,7 +1,8 @@
 """GPU box: seconds per cloud of the adaptive threshold search on the 190-block stand-in for longdress (thin shell @1024^3, level 4),
 c3p, with normals -- the reference's experiment setting opt_metrics ['d1_mse', 'd2_mse'] (ev_experiment.yml:47), and d1 only.
   round 2: any normals -> every metric on the host KD-tree pool ('decide' jobs);
-  round 3: d1_* from the GPU distance transforms, only the D2 tallies from the host pool ('tally' jobs, B->A neighbours queried once)."""
+  round 3: d1_* from the GPU distance transforms, only the D2 tallies from the host pool ('tally' jobs, B->A neighbours queried once);
+  round 4: d2_* on the GPU as well (nearest-index transforms, stated tie rule); PCC_D2_HOST=1 = the round-3 dispatch."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -30,8 +31,18 @@ def run(mets, host_only=False):
     if host_only:
         MTY.gpu_search_supported = keep
     return dt, out[1]
-run(['d1_mse'])                                      # warm-up (pool start, kernels)
+run(['d1_mse'])                                      # warm-up (kernels)
+run(['d1_mse', 'd2_mse'])
 for mets in (['d1_mse'], ['d1_mse', 'd2_mse']):
+    model.host_search_jobs = 0
     t_new, thr_new = run(mets)
-    t_old, thr_old = run(mets, host_only=True)
-    print(f'{mets}: round-3 dispatch {t_new:.2f} s / cloud, all-host (round-2 behaviour with normals) {t_old:.2f} s / cloud, {t_old / t_new:.1f}x; decisions equal: {thr_new == thr_old}; jobs {model.last_host_job_kind}')
+    jobs_new = model.host_search_jobs
+    os.environ['PCC_D2_HOST'] = '1'                  # round-3 dispatch: D2 tallies from the host KD-tree pool
+    run(mets) if mets[-1].startswith('d2') and 'warm' not in globals() else None
+    globals()['warm'] = True
+    t_r3, thr_r3 = run(mets)
+    del os.environ['PCC_D2_HOST']
+    same_d1 = [a[0] for a in thr_new] == [a[0] for a in thr_r3]
+    differ = sum(a != b for a, b in zip(thr_new, thr_r3))
+    print(f'{mets}: round 4 (all on the GPU, {jobs_new} host jobs) {t_new:.2f} s / cloud; round-3 dispatch (D2 on the host KD-tree pool) {t_r3:.2f} s / cloud, '
+          f'{t_r3 / t_new:.1f}x; d1 decisions equal: {same_d1}; blocks whose d2 decision differs (tie rule): {differ} of {len(thr_new)}')
