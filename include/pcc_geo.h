@@ -74,7 +74,10 @@ int pcc_ctx_num_cu(pcc_ctx* ctx);
 #define PCC_IMPL_GENERIC 1 /* direct convolution, any shape (reference-order fp32 FMA chain)      */
 #define PCC_IMPL_MFMA 2    /* force the direct MFMA implicit-GEMM path; PCC_ERR_ARG if not covered */
 #define PCC_IMPL_WINOGRAD 3 /* force Winograd F(2x2,3x3)+z on MFMA (Cin = Cout in {16,32,64}, k3 s1, W,H % 16 == 0); AUTO
-                              picks it when eligible (env PCC_NO_WINOGRAD=1 disables)                */
+                              picks it when eligible (env PCC_NO_WINOGRAD=1 disables); 16-channel layers take the split-bf16
+                              kernel (three bf16 pieces per fp32 operand, fp32-equivalent; env PCC_NO_SPLIT=1: exact-fp32 MFMA)  */
+#define PCC_IMPL_SPLIT 4    /* force the direct k3 stride-1 kernel with split-bf16 operands (Cin = Cout in {32,64}, W % 16 == 0);
+                              AUTO picks it for launches that fill the CUs (env PCC_NO_SPLIT_DIRECT=1 / PCC_NO_SPLIT=1 disable)    */
 
 typedef struct {
     int32_t N, D, H, W;    /* input batch and spatial size                                       */

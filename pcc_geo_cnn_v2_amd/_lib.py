@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('PCC_GEO_LIB', os.path.join(_HERE, 'libpcc_geo_hip.so'
 
 PCC_CONV_BIAS, PCC_CONV_RELU, PCC_CONV_ADD, PCC_CONV_CLIP01, PCC_CONV_F16 = 1, 2, 4, 8, 16
 PCC_CONV_IN16, PCC_CONV_OUT16, PCC_CONV_RES16 = 32, 64, 128          # fp16 storage inside the fp16 mode
-PCC_IMPL_AUTO, PCC_IMPL_GENERIC, PCC_IMPL_MFMA, PCC_IMPL_WINOGRAD = 0, 1, 2, 3
+PCC_IMPL_AUTO, PCC_IMPL_GENERIC, PCC_IMPL_MFMA, PCC_IMPL_WINOGRAD, PCC_IMPL_SPLIT = 0, 1, 2, 3, 4
 PCC_ROUND_FLOOR_HALF, PCC_ROUND_HALF_EVEN = 0, 1
 
 EXPORTS = [

@@ -94,6 +94,13 @@ bool pcc_wino_bf16_covers(const pcc_conv_desc* d);      // (given pcc_wino_eligi
 void pcc_wino_bf16_pack(int ngroups, const float* u_f32, float* out);
 int pcc_conv_wino_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* ub_packed, const float* bias,
                        const float* residual, float* out, hipStream_t st);
+// direct k3 stride-1 convolution with split-bf16 operands for Cin = Cout in {32, 64} (conv_split.hip)
+size_t pcc_split_packed_floats(int C);
+void pcc_split_pack(int C, const float* wlog, float* out);
+bool pcc_split_covers(const pcc_conv_desc* d);
+bool pcc_split_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d);
+int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, const float* residual,
+                   float* out, hipStream_t st);
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is set per DEVICE:
 // remember the (function, device) pairs this thread has configured.
 #include <utility>

@@ -1727,7 +1727,8 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
             if (pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && d->stride == 1)
                 return k3 * d->Cin * d->Cout + (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_U_FLOATS +
                        pcc_f16_packed_bytes(d->Cin) / 4 +     // + the fp16 fragments of conv_f16.hip
-                       (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_UB_FLOATS;     // + the split-bf16 image of U (conv_wino_bf16.hip)
+                       (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_UB_FLOATS +    // + the split-bf16 image of U (conv_wino_bf16.hip)
+                       (d->Cin >= 32 ? pcc_split_packed_floats(d->Cin) : 0);                // + the split image of the direct kernel (conv_split.hip)
             return k3 * d->Cin * d->Cout;
         case K_TR2: return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1);     // k3: second copy in the order of conv_tr2g_kernel
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
@@ -1782,10 +1783,12 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                     for (int ci = 0; ci < Cin; ++ci) for (int co = 0; co < Cout; ++co)
                         wlog[((((size_t)kz * 3 + ky) * 3 + kx) * Cin + ci) * Cout + co] = Wf(kz, ky, kx, ci, co);
                 pcc_f16_pack(Cin, wlog, (unsigned short*)(u + (size_t)NG * NCT * PCC_WINO_U_FLOATS));
+                // split-bf16 image of U behind the fp16 block, the direct kernel's split taps behind that
+                float* ub = u + (size_t)NG * NCT * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(Cin) / 4;
+                pcc_wino_bf16_pack(NG, u, ub);
+                if (Cin >= 32) pcc_split_pack(Cin, wlog, ub + (size_t)NG * NCT * PCC_WINO_UB_FLOATS);
                 free(wlog);
             }
-            // split-bf16 image of U behind the fp16 block
-            pcc_wino_bf16_pack(NG, u, u + (size_t)NG * NCT * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(Cin) / 4);
         }
     } else if (p.kind == K_TR2) {
         // consumption order of conv_tr2_kernel: [parity class (pz,py,px)][taps of the class (kz,ky,kx)][g][ct][lane][j]
@@ -1875,6 +1878,16 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
         PCC_REQUIRE(!(d->flags & PCC_CONV_OUT16) || d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_CONV_OUT16 is not implemented by the Winograd kernel (fp32)");
         const int fs = p.flip ? 1 : s;
         if (pcc_wino_channels(ci, co) && k == 3 && fs == 1) {
+            // 32- / 64-channel layers: direct convolution on the bf16 MFMA pipe with split operands (conv_split.hip) where it beats the
+            // fp32-MFMA Winograd kernel.  PCC_NO_SPLIT=1 (all split paths) / PCC_NO_SPLIT_DIRECT=1 (this one) for A/B runs
+            const float* w_split = w_packed + (size_t)27 * ci * co + (size_t)(ci / 16) * (co / 16) * (PCC_WINO_U_FLOATS + PCC_WINO_UB_FLOATS) + pcc_f16_packed_bytes(ci) / 4;
+            if (d->impl == PCC_IMPL_SPLIT) {
+                PCC_REQUIRE(ci >= 32 && pcc_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)), "pcc_conv3d: PCC_IMPL_SPLIT covers fp32 k3 stride-1 layers with Cin = Cout in {32, 64}, W % 16 == 0");
+                return pcc_conv_split(ctx, d, in, w_split, bias, residual, out, st);
+            }
+            if (d->impl == PCC_IMPL_AUTO && ci >= 32 && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && getenv("PCC_NO_SPLIT") == nullptr &&
+                getenv("PCC_NO_SPLIT_DIRECT") == nullptr && pcc_split_covers(d) && pcc_split_preferred(ctx, d))
+                return pcc_conv_split(ctx, d, in, w_split, bias, residual, out, st);
             static const bool no_wino = getenv("PCC_NO_WINOGRAD") != nullptr;
             static const bool no_wino32 = getenv("PCC_NO_WINOGRAD32") != nullptr;
             static const bool wino64 = getenv("PCC_NO_WINOGRAD64") == nullptr;

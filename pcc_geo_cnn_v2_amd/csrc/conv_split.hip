@@ -1,0 +1,352 @@
+// Direct 3x3x3 stride-1 convolution on the bf16 MFMA pipe with fp32-EQUIVALENT operands, Cin = Cout in {32, 64} (round 4).
+//
+// The multi-group k3 stride-1 layers of /root/reference/src/model_transforms.py:62-81 (32 -> 32 @32^3 / 16^3, 64 -> 64 @16^3) ran
+// on conv16_wino_cin_kernel (Winograd, exact-fp32 MFMA, 0.58 - 0.70 of the 157 TFLOP/s pipe executed).  The split-bf16 Winograd
+// kernel (conv_wino_bf16.hip) does not extend to them: its split weights are 96 KB per (cin group, cout group) and a launch
+// needs all cin groups of a cout group in LDS.  A DIRECT convolution has no such coupling, and on the bf16 pipe its 2.25x larger
+// multiply count is cheaper than Winograd on the fp32 pipe: three v_mfma_f32_16x16x32_bf16 (48 cycles) per tap, 16 voxels and
+// (16 cin, 16 cout) pair against 4 x 32 / 2.25 = 57 cycles of fp32 Winograd MFMAs -- with none of Winograd's VALU work: no input /
+// output transforms, no AccVGPR shuffles, and the operand split is paid ONCE per input element when the tile is staged
+// (every staged element then feeds 27 taps x Cout multiply-adds) instead of once per (tile, point) element.
+//
+// Operand split as in conv_wino_bf16.hip: x = h + m + l exactly (three bf16 pieces), six product terms
+//     acc += [Wh | Wm] . [dh | dm]   (hh + mm);   acc += [Wh | Wm] . [dl | dh]   (hl + mh);   acc += [Wl | Wh] . [dh | dm]   (lh + hm)
+// fp32 accumulation in a fixed order (cin group -> tap -> the three MFMAs): bit-deterministic, independent of tile position and
+// launch geometry.
+//
+// Structure = conv_fwd_kernel's k3 path (conv_mfma.hip): workgroup = 4 waves = tile of 2 x 8 x 16 output voxels; a wave owns the
+// R = 8 rows of 16 voxels of one z plane and HALF of the cout tiles.  (First version: 4 rows x all cout tiles per wave -- every wave
+// then pulls all weights of a tap from L2, 42 B/clk/CU, and the MFMA pipe sat at 0.46 / 0.64 busy waiting for them; with 8 rows per
+// weight fragment it is 21 B/clk/CU, and the LDS serves the 2 x 8 row fragments per tap at 85 - 170 B/clk of its 256.)  Per cin
+// group the haloed input tile (4 x 10 x 18 voxels x 16 channels) is staged global -> registers -> split -> LDS, 160 bytes per voxel:
+// [B1: 4 cin quads x 16 B][B2: 4 x 16 B][32 B pad] -- the stride 40 dwords = 8 * 5 keeps the 16 lanes of every ds_read_b128 group
+// on distinct bank quads, like the 24-dword stride of the fp32 kernel.  Weights stream from L2 through a register ring two taps
+// ahead; the next group's staging loads and the residual rows ride in the tap sections.
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+
+namespace pccsplit {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ u32x4 buf_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// only VALU / SALU may cross: memory operations and MFMAs keep their written order (as PCC_PIN_MEM_MFMA in conv_mfma.hip)
+#define PCC_SPLIT_PIN() __builtin_amdgcn_sched_barrier(0x406)
+
+// Two staging items (2 x 4 input channels of a voxel each): fp32 -> B1 = [dh | dm], B2 = [dl | dh] each.  ONE asm block, because
+// v_dot2c_f32_bf16 is a DOT instruction: a different VALU op that reads its result needs 3 wait states behind it
+// (GCNHazardRecognizer: DotWriteDifferentVALURead) and the hazard recogniser cannot see into inline asm.  Inside the block every
+// reader sits >= 3 instructions behind its writer; K0 / K1 = the bf16 pairs {-1, 0} / {0, -1}: x -= lo(h) / hi(h), exactly.
+__device__ __forceinline__ void split_items2(u32x4& p_b1, u32x4& p_b2, u32x4& q_b1, u32x4& q_b2, const f32x4& pv, const f32x4& qv) {
+    float a = pv[0], b = pv[1], c = pv[2], d = pv[3], e = qv[0], f = qv[1], g = qv[2], h = qv[3];
+    unsigned ph01, ph23, pm01, pm23, pl01, pl23, pg01, pg23, qh01, qh23, qm01, qm23, ql01, ql23, qg01, qg23;
+    asm volatile(
+        "v_cvt_pk_bf16_f32 %8, %0, %1\n\tv_cvt_pk_bf16_f32 %9, %2, %3\n\tv_cvt_pk_bf16_f32 %16, %4, %5\n\tv_cvt_pk_bf16_f32 %17, %6, %7\n\t"
+        "v_cvt_pk_bf16_f32 %14, %0, %1\n\tv_cvt_pk_bf16_f32 %15, %2, %3\n\tv_cvt_pk_bf16_f32 %22, %4, %5\n\tv_cvt_pk_bf16_f32 %23, %6, %7\n\t"
+        "v_dot2c_f32_bf16 %0, %24, %8\n\tv_dot2c_f32_bf16 %1, %25, %8\n\tv_dot2c_f32_bf16 %2, %24, %9\n\tv_dot2c_f32_bf16 %3, %25, %9\n\t"
+        "v_dot2c_f32_bf16 %4, %24, %16\n\tv_dot2c_f32_bf16 %5, %25, %16\n\tv_dot2c_f32_bf16 %6, %24, %17\n\tv_dot2c_f32_bf16 %7, %25, %17\n\t"
+        "v_cvt_pk_bf16_f32 %10, %0, %1\n\tv_cvt_pk_bf16_f32 %11, %2, %3\n\tv_cvt_pk_bf16_f32 %18, %4, %5\n\ts_nop 0\n\tv_cvt_pk_bf16_f32 %19, %6, %7\n\t"
+        "v_dot2c_f32_bf16 %0, %24, %10\n\tv_dot2c_f32_bf16 %1, %25, %10\n\tv_dot2c_f32_bf16 %2, %24, %11\n\tv_dot2c_f32_bf16 %3, %25, %11\n\t"
+        "v_dot2c_f32_bf16 %4, %24, %18\n\tv_dot2c_f32_bf16 %5, %25, %18\n\tv_dot2c_f32_bf16 %6, %24, %19\n\tv_dot2c_f32_bf16 %7, %25, %19\n\t"
+        "v_cvt_pk_bf16_f32 %12, %0, %1\n\tv_cvt_pk_bf16_f32 %13, %2, %3\n\tv_cvt_pk_bf16_f32 %20, %4, %5\n\ts_nop 0\n\tv_cvt_pk_bf16_f32 %21, %6, %7\n\ts_nop 2"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h),
+          "=&v"(ph01), "=&v"(ph23), "=&v"(pm01), "=&v"(pm23), "=&v"(pl01), "=&v"(pl23), "=&v"(pg01), "=&v"(pg23),
+          "=&v"(qh01), "=&v"(qh23), "=&v"(qm01), "=&v"(qm23), "=&v"(ql01), "=&v"(ql23), "=&v"(qg01), "=&v"(qg23)
+        : "s"(0x0000bf80u), "s"(0xbf800000u));
+    p_b1 = (u32x4){ph01, ph23, pm01, pm23}; p_b2 = (u32x4){pl01, pl23, pg01, pg23};
+    q_b1 = (u32x4){qh01, qh23, qm01, qm23}; q_b2 = (u32x4){ql01, ql23, qg01, qg23};
+}
+
+
+struct SplitArgs {
+    const float* in;
+    const float* w;      // split image: [cin group][tap][cout tile][operand][lane][8 bf16]
+    const float* bias;
+    const float* res;
+    float* out;
+    int N, D, H, W;
+    int ntz, nty, ntx;
+    int flags, ocs, oco;
+};
+
+template <int CH, int TZ, int TY, int R, int CTW>
+struct SplitCfg {
+    static constexpr int NG = CH / 16, NCT = CH / 16;
+    static constexpr int NCG = NCT / CTW;               // waves also split the cout tiles
+    static constexpr int NW = TZ * (TY / R) * NCG, NT = NW * 64;
+    static constexpr int LZ = TZ + 2, LY = TY + 2, LX = 18;
+    static constexpr int VS = 40;                       // dwords per voxel in LDS: B1 (16) + B2 (16) + 8 pad
+    static constexpr int NV = LZ * LY * LX;
+    static constexpr int LDS_BYTES = NV * VS * 4;
+    static constexpr int ITEMS = ((NV * 4 + NT - 1) / NT + 1) & ~1;      // (voxel, cin quad) items per thread, even: split two at a time
+    static constexpr int RING = 3;                      // weight ring depth (taps); 27 % RING == 0
+    static_assert(TY % R == 0 && NCT % CTW == 0 && 27 % RING == 0 && ITEMS <= 26, "bad tile");
+};
+
+template <int CH, int TZ, int TY, int R, int CTW>
+__global__ void __launch_bounds__((SplitCfg<CH, TZ, TY, R, CTW>::NT), (SplitCfg<CH, TZ, TY, R, CTW>::LDS_BYTES <= 80 * 1024 ? 2 : 1))
+conv_k3s1_split_kernel(SplitArgs a) {
+    using C = SplitCfg<CH, TZ, TY, R, CTW>;
+    constexpr int NTAP = 27, RING = C::RING;
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int v = lane & 15, cq = lane >> 4;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = t % a.ntx; t /= a.ntx;
+    const int ty = t % a.nty; t /= a.nty;
+    const int tz = t % a.ntz;
+    const int n = t / a.ntz;
+    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+    const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int ct0 = (wave % C::NCG) * CTW;               // first cout tile of this wave
+    const int w_yg = (wave / C::NCG) % (TY / R), w_z = wave / C::NCG / (TY / R);
+    const int ly0 = w_yg * R, lx0 = v;
+    const unsigned* lbase = lds + ((w_z * C::LY + ly0) * C::LX + lx0) * C::VS + cq * 4;
+    constexpr int ROW_OFF = C::LX * C::VS;
+
+    f32x4 acc[R][CTW];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* inb = a.in + (size_t)n * a.D * a.H * a.W * CH;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)a.D * a.H * a.W * CH * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(C::NG * NTAP * C::NCT) * 2048u);
+    const unsigned wlane = lane * 16;
+    const int q_last = C::NG * NTAP - 1;
+    auto tap_off = [](int kz, int ky, int kx) { return ((kz * C::LY + ky) * C::LX + kx) * C::VS; };
+
+    unsigned soff[C::ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::ITEMS; ++it) {
+        const int item = it * C::NT + tid;
+        const int u = item >> 2, q = item & 3;
+        const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
+        const int ly = rem / C::LX, lx = rem - ly * C::LX;
+        const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
+        const bool ok = (item < C::NV * 4) & (gz >= 0) & (gz < a.D) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+        soff[it] = ok ? (unsigned)(((gz * a.H + gy) * a.W + gx) * CH + q * 4) * 4u : kOOB;
+    }
+    // split the staged fp32 items into their bf16 pieces and write B1 / B2 of (voxel, cin quad)
+    auto commit = [&](const f32x4 (&stg)[C::ITEMS]) {
+#pragma unroll
+        for (int it = 0; it < C::ITEMS; it += 2) {
+            u32x4 p1, p2, q1, q2;
+            split_items2(p1, p2, q1, q2, stg[it], stg[it + 1]);
+            const int i0 = it * C::NT + tid, i1 = (it + 1) * C::NT + tid;
+            if (i0 < C::NV * 4) {
+                *reinterpret_cast<u32x4*>(lds + (i0 >> 2) * C::VS + (i0 & 3) * 4) = p1;
+                *reinterpret_cast<u32x4*>(lds + (i0 >> 2) * C::VS + 16 + (i0 & 3) * 4) = p2;
+            }
+            if (i1 < C::NV * 4) {
+                *reinterpret_cast<u32x4*>(lds + (i1 >> 2) * C::VS + (i1 & 3) * 4) = q1;
+                *reinterpret_cast<u32x4*>(lds + (i1 >> 2) * C::VS + 16 + (i1 & 3) * 4) = q2;
+            }
+        }
+    };
+
+    constexpr int NRES = R * CTW;
+    constexpr int RES0 = 27 - NRES;
+    static_assert(NRES <= 27, "residual prefetch is spread over the tap sections");
+    f32x4 stg[C::ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::ITEMS; ++it) stg[it] = buf_load4(rin, soff[it], 0);
+    u32x4 wf1[RING][CTW], wf2[RING][CTW];
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            wf1[r][ct] = buf_load4u(rw, wlane, (unsigned)(min(r, q_last) * C::NCT + ct0 + ct) * 2048u);
+            wf2[r][ct] = buf_load4u(rw, wlane, (unsigned)(min(r, q_last) * C::NCT + ct0 + ct) * 2048u + 1024u);
+        }
+    commit(stg);
+    __syncthreads();
+
+    const int gzo = oz0 + w_z;
+    const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + (size_t)n * a.D * a.H * a.W * CH : a.in,
+                                                  has_res ? (unsigned)a.D * a.H * a.W * CH * 4u : 0u);
+    f32x4 resv[R][CTW];
+
+#pragma unroll 1
+    for (int g = 0; g < C::NG; ++g) {
+        const unsigned gnext = (unsigned)min(g + 1, C::NG - 1) * 64u;     // last group: harmless re-read
+        const bool last = g == C::NG - 1;
+        u32x4 b1[2][R], b2[2][R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            b1[0][i] = *reinterpret_cast<const u32x4*>(lbase + i * ROW_OFF);
+            b2[0][i] = *reinterpret_cast<const u32x4*>(lbase + i * ROW_OFF + 16);
+        }
+#pragma unroll
+        for (int ts = 0; ts < NTAP; ++ts) {
+            {
+                const int q = min(g * NTAP + ts + RING - 1, q_last);
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) {
+                    wf1[(ts + RING - 1) % RING][ct] = buf_load4u(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 2048u);
+                    wf2[(ts + RING - 1) % RING][ct] = buf_load4u(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 2048u + 1024u);
+                }
+                const int tn = (ts + 1 < NTAP) ? ts + 1 : ts;   // last tap: harmless re-read
+                const int toff = tap_off(tn / 9, (tn / 3) % 3, tn % 3);
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    b1[(ts + 1) & 1][i] = *reinterpret_cast<const u32x4*>(lbase + toff + i * ROW_OFF);
+                    b2[(ts + 1) & 1][i] = *reinterpret_cast<const u32x4*>(lbase + toff + i * ROW_OFF + 16);
+                }
+                if (ts < C::ITEMS) stg[ts] = buf_load4(rin, soff[ts], gnext);
+                if (ts >= RES0 && ts < RES0 + NRES) {
+                    const int i = (ts - RES0) / CTW, ct = (ts - RES0) % CTW;
+                    const int gy = oy0 + ly0 + i, gx = ox0 + lx0;
+                    const bool ok = last & has_res & (gzo < a.D) & (gy < a.H) & (gx < a.W);
+                    const unsigned off = (unsigned)(((gzo * a.H + gy) * a.W + gx) * CH + (ct0 + ct) * 16 + cq * 4) * 4u;
+                    resv[i][ct] = buf_load4(rres, ok ? off : kOOB, 0);
+                }
+            }
+            // three MFMAs per (row, cout tile); term outermost: consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct)
+                        acc[i][ct] = mfma_bf16(tm == 2 ? wf2[ts % RING][ct] : wf1[ts % RING][ct], tm == 1 ? b2[ts & 1][i] : b1[ts & 1][i], acc[i][ct]);
+            PCC_SPLIT_PIN();
+        }
+        if (!last) {
+            __syncthreads();   // every wave finished reading group g
+            commit(stg);
+            __syncthreads();
+        }
+    }
+    // ---- epilogue (residual already in registers)
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gy = oy0 + ly0 + i, gx = ox0 + lx0;
+        if (gzo < a.D && gy < a.H && gx < a.W) {
+            const size_t vox = (((size_t)n * a.D + gzo) * a.H + gy) * a.W + gx;
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+                f32x4 o = acc[i][ct];
+                const int c0 = (ct0 + ct) * 16 + cq * 4;
+                if (a.flags & PCC_CONV_BIAS) o += *reinterpret_cast<const f32x4*>(a.bias + c0);
+                if (a.flags & PCC_CONV_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                if (has_res) o += resv[i][ct];
+                if (a.flags & PCC_CONV_CLIP01) {
+                    o.x = fminf(fmaxf(o.x, 0.f), 1.f); o.y = fminf(fmaxf(o.y, 0.f), 1.f);
+                    o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
+                }
+                *reinterpret_cast<f32x4*>(a.out + vox * a.ocs + a.oco + c0) = o;
+            }
+        }
+    }
+}
+
+}  // namespace pccsplit
+
+using namespace pccsplit;
+
+// ---- host: split image of the logical forward weights.  wlog: [kz][ky][kx][ci][co] (already flipped for transposed layers);
+//      out: [cin group][tap][cout tile][operand][lane][8 bf16]; operand 0 = [Wh c0..c3 | Wm], 1 = [Wl | Wh]; cin = 16 g + 4 (lane >> 4) + c,
+//      cout = 16 ct + (lane & 15)
+static inline unsigned short bf16_rn(float v) {
+    unsigned b;
+    memcpy(&b, &v, 4);
+    if ((b & 0x7f800000u) == 0x7f800000u) return (unsigned short)(b >> 16);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (unsigned short)(b >> 16);
+}
+static inline float bf16_f(unsigned short h) {
+    const unsigned b = (unsigned)h << 16;
+    float v;
+    memcpy(&v, &b, 4);
+    return v;
+}
+size_t pcc_split_packed_floats(int C) { return (size_t)(C / 16) * 27 * (C / 16) * 2 * 64 * 4; }
+void pcc_split_pack(int C, const float* wlog, float* out) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    const int NG = C / 16;
+    for (int g = 0; g < NG; ++g)
+        for (int tap = 0; tap < 27; ++tap)
+            for (int ct = 0; ct < NG; ++ct)
+                for (int lane = 0; lane < 64; ++lane) {
+                    unsigned short h[4], m[4], l[4];
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = wlog[((size_t)tap * C + g * 16 + 4 * (lane >> 4) + c) * C + ct * 16 + (lane & 15)];
+                        h[c] = bf16_rn(x);
+                        const float r1 = x - bf16_f(h[c]);
+                        m[c] = bf16_rn(r1);
+                        l[c] = bf16_rn(r1 - bf16_f(m[c]));
+                    }
+                    unsigned short* a1 = o + (((((size_t)g * 27 + tap) * NG + ct) * 2 + 0) * 64 + lane) * 8;
+                    unsigned short* a2 = o + (((((size_t)g * 27 + tap) * NG + ct) * 2 + 1) * 64 + lane) * 8;
+                    for (int c = 0; c < 4; ++c) { a1[c] = h[c]; a1[4 + c] = m[c]; a2[c] = l[c]; a2[4 + c] = h[c]; }
+                }
+}
+
+bool pcc_split_covers(const pcc_conv_desc* d) {
+    if (!(d->Cin == d->Cout && (d->Cin == 32 || d->Cin == 64) && d->k == 3 && d->stride == 1)) return false;
+    if (d->W % 16) return false;
+    const int ocs = d->out_cstride ? d->out_cstride : d->Cout;
+    if (ocs % 4 || d->out_coffset % 4) return false;
+    return (double)d->D * d->H * d->W * d->Cin * 4.0 < 2147483648.0;        // one image per buffer descriptor
+}
+
+// AUTO takes this path for the 64-channel layers when the launch fills the CUs (tile = 2 x 4 x 16 voxels, two workgroups per CU).
+// Measured (batch 32, tools/bench_one.py): 64 -> 64 @16^3 128 us against 138 - 146 us for conv16_wino_cin_kernel<4> and 234 us for the
+// exact-fp32 direct kernel; 32 -> 32 @32^3 333 us against 241 us (Winograd) and 468 us (fp32 direct): with R x CTW = 4 x 1 MFMA
+// groups per operand fetch the 32-channel launch is bound by its operand traffic (5 GB of weight fragments from L2, 15 GB of input
+// fragments from LDS per launch -- MFMA busy 0.29 - 0.46), so the Winograd kernel keeps those layers.
+bool pcc_split_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d) {
+    const long tiles = (long)d->N * ((d->D + 1) / 2) * ((d->H + 3) / 4) * (d->W / 16);
+    return d->Cin == 64 && tiles >= 2L * ctx->num_cu;
+}
+
+int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, const float* residual,
+                   float* out, hipStream_t st) {
+    PCC_REQUIRE(pcc_split_covers(d), "pcc_conv_split: shape not covered");
+    SplitArgs a;
+    a.in = in; a.w = w_split; a.bias = bias; a.res = residual; a.out = out;
+    a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
+    a.flags = d->flags; a.ocs = d->out_cstride ? d->out_cstride : d->Cout; a.oco = d->out_coffset;
+    // tile 2 x 4 x 16 (69 KB of LDS, two workgroups per CU: the second wave of a SIMD covers the first one's LDS / L2 waits) or
+    // 2 x 8 x 16 (115 KB, one workgroup per CU, fewer halo voxels); PCC_SPLIT_TILE=8 selects the large one (A/B)
+    static const bool big = getenv("PCC_SPLIT_TILE") != nullptr && atoi(getenv("PCC_SPLIT_TILE")) == 8;
+#define PCC_SPLIT_LAUNCH(CH, TZ, TY, R)                                                                            \
+    {                                                                                                              \
+        using C = SplitCfg<CH, TZ, TY, R, CH / 32>;                                                                \
+        a.ntz = (d->D + TZ - 1) / TZ; a.nty = (d->H + TY - 1) / TY; a.ntx = d->W / 16;                             \
+        const int grid = d->N * a.ntz * a.nty * a.ntx;                                                             \
+        const void* kern = (const void*)conv_k3s1_split_kernel<CH, TZ, TY, R, CH / 32>;                            \
+        { const int rc = pcc_enable_big_lds(kern, C::LDS_BYTES); if (rc != PCC_OK) return rc; }                    \
+        hipLaunchKernelGGL((conv_k3s1_split_kernel<CH, TZ, TY, R, CH / 32>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, st, a); \
+    }
+    if (d->Cin == 32) { if (big) PCC_SPLIT_LAUNCH(32, 2, 8, 8) else PCC_SPLIT_LAUNCH(32, 2, 4, 4) }
+    else { if (big) PCC_SPLIT_LAUNCH(64, 2, 8, 8) else PCC_SPLIT_LAUNCH(64, 2, 4, 4) }
+#undef PCC_SPLIT_LAUNCH
+    PCC_CHECK_HIP(hipGetLastError());
+    return PCC_OK;
+}

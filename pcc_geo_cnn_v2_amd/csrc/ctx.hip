@@ -108,8 +108,8 @@ PCC_API int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
         PCC_REQUIRE(fast_ok && d->impl == PCC_IMPL_AUTO, "pcc_conv3d: fp16 storage needs the packed weights and PCC_IMPL_AUTO");
         return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
     }
-    if (d->impl == PCC_IMPL_MFMA || d->impl == PCC_IMPL_WINOGRAD) {
-        PCC_REQUIRE(fast_ok, "pcc_conv3d: PCC_IMPL_MFMA/WINOGRAD requested but shape not covered or w_packed NULL");
+    if (d->impl == PCC_IMPL_MFMA || d->impl == PCC_IMPL_WINOGRAD || d->impl == PCC_IMPL_SPLIT) {
+        PCC_REQUIRE(fast_ok, "pcc_conv3d: PCC_IMPL_MFMA/WINOGRAD/SPLIT requested but shape not covered or w_packed NULL");
         return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
     }
     if (d->impl == PCC_IMPL_AUTO && fast_ok) return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);

@@ -433,3 +433,41 @@ def test_fp16_storage_flags_are_checked(ctx):
     assert L.lib().pcc_conv3d(*args(d)) == -1 and b'fp16 mode' in L.lib().pcc_last_error()
     d = layer.desc(1, 4, 24, 16, L.PCC_CONV_IN16 | L.PCC_CONV_F16)   # H not a multiple of 16
     assert L.lib().pcc_conv3d(*args(d)) == -1
+
+
+SPLIT_CASES = [
+    # N, D, H, W, C, tr, bias, relu, res
+    (2, 8, 16, 16, 32, False, True, True, True), (1, 6, 8, 32, 32, True, False, False, False), (3, 5, 24, 16, 64, True, True, True, True),
+    (1, 16, 16, 16, 64, False, True, False, False), (2, 3, 7, 16, 32, False, True, True, True),
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_direct_split_bf16_conv_matches_oracle(ctx, oracle, case):
+    """conv_split.hip (direct k3 stride-1 convolution, split-bf16 operands on the bf16 MFMA pipe, Cin = Cout in {32, 64}) against the
+    C oracle: partial tiles in z and y, every epilogue flag, forward and (flipped) transposed layers; the same tolerance as the
+    exact-fp32 MFMA kernels."""
+    N, D, H, W, C, tr, bias, relu, res = case
+    _run(ctx, oracle, N, D, H, W, C, C, 3, 1, tr, bias, relu, res, L.PCC_IMPL_SPLIT, seed=31)
+
+
+def test_direct_split_bf16_conv_is_deterministic_geometry_invariant_and_as_accurate_as_fp32(ctx, oracle):
+    rng = np.random.default_rng(41)
+    C = 32
+    w = (rng.standard_normal((3, 3, 3, C, C)) / np.sqrt(27 * C)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((3, 10, 16, 32, C)).astype(np.float32)).to(ctx.device)
+    layer = ops.ConvLayer(w, b, 1, False, True)
+    a = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_SPLIT)
+    assert torch.equal(a, ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_SPLIT))
+    assert torch.equal(a[2:3], ops.conv3d(ctx, x[2:3].contiguous(), layer, impl=L.PCC_IMPL_SPLIT))
+    assert torch.equal(a[:, 2:8], ops.conv3d(ctx, x[:, 1:9].contiguous(), layer, impl=L.PCC_IMPL_SPLIT)[:, 1:7])      # other tile origin in z
+    ref = oracle.conv3d(x.cpu().numpy(), w, b, 1, True)
+    direct = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA).cpu().numpy()
+    e_split, e_f32 = np.abs(a.cpu().numpy() - ref).max(), np.abs(direct - ref).max()
+    print(f'direct split-bf16 max err {e_split:.2e}, exact-fp32 direct kernel {e_f32:.2e}')
+    assert e_split <= 8e-6 * (1 + np.abs(ref).max()) and e_split <= 3 * e_f32 + 1e-6
+    nobias = ops.ConvLayer(w, None, 1, False, False)
+    base = ops.conv3d(ctx, x, nobias, impl=L.PCC_IMPL_SPLIT)
+    for e in (-50, 30):
+        assert torch.equal(ops.conv3d(ctx, x * (2.0 ** e), nobias, impl=L.PCC_IMPL_SPLIT), base * (2.0 ** e)), e
