@@ -315,14 +315,16 @@ bool pcc_split_covers(const pcc_conv_desc* d) {
     return (double)d->D * d->H * d->W * d->Cin * 4.0 < 2147483648.0;        // one image per buffer descriptor
 }
 
-// AUTO takes this path for the 64-channel layers when the launch fills the CUs (tile = 2 x 4 x 16 voxels, two workgroups per CU).
+// AUTO takes this path for the 64-channel layers (tile = 2 x 4 x 16 voxels, two workgroups per CU).
 // Measured (batch 32, tools/bench_one.py): 64 -> 64 @16^3 128 us against 138 - 146 us for conv16_wino_cin_kernel<4> and 234 us for the
 // exact-fp32 direct kernel; 32 -> 32 @32^3 333 us against 241 us (Winograd) and 468 us (fp32 direct): with R x CTW = 4 x 1 MFMA
 // groups per operand fetch the 32-channel launch is bound by its operand traffic (5 GB of weight fragments from L2, 15 GB of input
 // fragments from LDS per launch -- MFMA busy 0.29 - 0.46), so the Winograd kernel keeps those layers.
+// The choice depends on the layer shape ONLY, never on the batch: encoder and decoder run with different batch sizes and must produce
+// the same bits (tests/test_codec_gpu.py::test_blocks_128_cubed_roundtrip_and_layer_parity caught a batch-dependent rule).
 bool pcc_split_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d) {
-    const long tiles = (long)d->N * ((d->D + 1) / 2) * ((d->H + 3) / 4) * (d->W / 16);
-    return d->Cin == 64 && tiles >= 2L * ctx->num_cu;
+    (void)ctx;
+    return d->Cin == 64;
 }
 
 int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, const float* residual,
