@@ -81,6 +81,12 @@ bool pcc_tr2m_eligible(const pcc_conv_desc* d);
 bool pcc_tr2m_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d);
 int pcc_conv_tr2m(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_tr2g, const float* bias, float* out,
                   hipStream_t st);
+// the same march with split-bf16 operands for 32 -> 16 (conv_tr2m_bf16.hip)
+size_t pcc_tr2m_bf16_packed_floats(int Cin, int Cout);
+void pcc_tr2m_bf16_pack(int Cin, int Cout, const float* w_tr2g, float* out);
+bool pcc_tr2m_bf16_covers(const pcc_conv_desc* d);
+int pcc_conv_tr2m_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
+                       hipStream_t st);
 // fp16-storage k3 stride-1 kernel for Cin = Cout in {16, 32} (conv_f16.hip), PCC_CONV_IN16 layers
 bool pcc_f16_eligible(const pcc_conv_desc* d);
 size_t pcc_f16_packed_bytes(int C);

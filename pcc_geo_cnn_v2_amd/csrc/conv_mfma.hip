@@ -1730,7 +1730,8 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
                        (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_UB_FLOATS +    // + the split-bf16 image of U (conv_wino_bf16.hip)
                        (d->Cin >= 32 ? pcc_split_packed_floats(d->Cin) : 0);                // + the split image of the direct kernel (conv_split.hip)
             return k3 * d->Cin * d->Cout;
-        case K_TR2: return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1);     // k3: second copy in the order of conv_tr2g_kernel
+        case K_TR2:     // k3: second copy in the order of conv_tr2g_kernel; 32 -> 16: + its split-bf16 image (conv_tr2m_bf16.hip)
+            return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1) + (d->k == 3 && d->Cin == 32 && d->Cout == 16 ? pcc_tr2m_bf16_packed_floats(32, 16) : 0);
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
         case K_COUT1: return k3 * d->Cin;
         case K_COUT1M: return 2 * 64 * 4;
@@ -1816,6 +1817,7 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                                     pg[((((size_t)g * 27 + sq) * NCT + ct) * 64 + lane) * 4 + j] =
                                         Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
             }
+            if (Cin == 32 && Cout == 16) pcc_tr2m_bf16_pack(Cin, Cout, pg, pg + (size_t)27 * Cin * Cout);
         }
     } else if (p.kind == K_CIN1) {
         // [kz][ky][kxg][ct][lane] : kx = kxg*4 + (lane>>4) (zero beyond k), cout = ct*16 + (lane&15)
@@ -1909,8 +1911,12 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
     } else if (p.kind == K_TR2) {
         // z-marching kernel (conv_tr2m.hip) for the 32 -> 16 / 64 -> 32 layers on grids of 16-multiples.  PCC_NO_TR2M=1 keeps the
         // tiled conv_tr2g_kernel, PCC_TR2M=1 takes the marching kernel wherever it is eligible (A/B runs, tests)
-        if (getenv("PCC_NO_TR2M") == nullptr && (getenv("PCC_TR2M") != nullptr ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d)))
+        if (getenv("PCC_NO_TR2M") == nullptr && (getenv("PCC_TR2M") != nullptr ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {
+            // 32 -> 16: split-bf16 operands on the bf16 MFMA pipe (conv_tr2m_bf16.hip); PCC_NO_SPLIT=1 / PCC_NO_SPLIT_TR2=1: exact fp32 (A/B)
+            if (pcc_tr2m_bf16_covers(d) && getenv("PCC_NO_SPLIT") == nullptr && getenv("PCC_NO_SPLIT_TR2") == nullptr)
+                return pcc_conv_tr2m_bf16(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, st);
             return pcc_conv_tr2m(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
+        }
         PCC_CASE_TR2(64, 64, 3) PCC_CASE_TR2(64, 32, 3) PCC_CASE_TR2(32, 16, 3) PCC_CASE_TR2(32, 32, 3)
         PCC_CASE_TR2(32, 32, 5)
     } else if (p.kind == K_CIN1) {
