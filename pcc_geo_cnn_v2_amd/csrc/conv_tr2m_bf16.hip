@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
 
     f32x4 E[2][4][4], O[4][4];                        // accumulators [set][class py * 2 + px][row]
     u32x4 b1[2][2][4], b2[2][2][4];                   // split B operands [dyi][dxi][row] of the current micro-step: [dh | dm], [dl | dh]
-    u32x4 wf1[2], wf2[2];                             // weight fragment double buffer: [Wh | Wm], [Wl | Wh]
+    u32x4 wf1[3], wf2[3];                             // weight fragment ring, two taps ahead (a tap is 12 MFMAs = 192 cycles: one tap does not cover an LDS read): [Wh | Wm], [Wl | Wh]
     // the 16 fp32 vectors of the micro-step are read from LDS and split two at a time (one hazard-safe asm block per pair)
     auto load_b = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
         wf2[slot] = ldsu(wa + (unsigned)(sq * 2048 + 1024));
     };
     load_b();
-    load_w(0, tap_of(18).sq);                         // step 0 is the halo plane: its first tap is 18
+    load_w(0, tap_of(18).sq); load_w(1, tap_of(19).sq);      // step 0 is the halo plane: its first tap is 18 (ring slot = (t - T0) % 3)
 
     // wave-uniform march state
     int s = 0, c = 0;                                 // input plane step / cin group of the current micro-step
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
             constexpr Tap T = tap_of(t);
             constexpr Tap Tn = tap_of(t + 1 < 27 ? t + 1 : 0);
             // weight fragment of the next tap (wraps to tap 0 of the next micro-step: loaded after the barrier instead)
-            if constexpr (t + 1 < 27) load_w((t + 1) & 1, Tn.sq);
+            if constexpr (t + 2 < 27) load_w((t + 2 - T0) % 3, tap_of(t + 2).sq);
             constexpr bool open = FIRST && T.opens && T.kz != 0;     // first tap of a class of the odd / even_next set in this plane
             // three MFMAs per row, term outermost: a dependent MFMA is four issue slots away
 #pragma unroll
@@ -250,9 +250,11 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     f32x4& acc = T.kz == 0 ? E[PH][T.cls][i] : T.kz == 1 ? O[T.cls][i] : E[PH ^ 1][T.cls][i];
-                    acc = mfma_bf16(tm == 2 ? wf2[t & 1] : wf1[t & 1], tm == 1 ? b2[T.dyi][T.dxi][i] : b1[T.dyi][T.dxi][i], (open && tm == 0) ? bias_l : acc);
+                    acc = mfma_bf16(tm == 2 ? wf2[(t - T0) % 3] : wf1[(t - T0) % 3], tm == 1 ? b2[T.dyi][T.dxi][i] : b1[T.dyi][T.dxi][i], (open && tm == 0) ? bias_l : acc);
                 }
+#ifndef PCC_TR2MB_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
+#endif
             if constexpr (FIRST && !HALO) {
                 if constexpr (t < 8) {
                     finish(ph_tag, std::integral_constant<int, 2 * t>{}, rout, ost[t & 1][0]);
@@ -280,8 +282,8 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
         if (++c1 == NG) { c1 = 0; ++s1; tile_pl += HWI - 64 * NG; }
         load_b();
         // first weight fragment of the next micro-step (buffer parity follows its first tap: 0, or 18 inside the halo plane)
-        if (s == 0) load_w(0, tap_of(18).sq);
-        else load_w(0, tap_of(0).sq);
+        if (s == 0) { load_w(0, tap_of(18).sq); load_w(1, tap_of(19).sq); }
+        else { load_w(0, tap_of(0).sq); load_w(1, tap_of(1).sq); }
     };
     // one input plane = NG micro-steps, unrolled (a run-time loop over the middle ones made the register allocator shuttle the
     // accumulators between AccVGPRs and VGPRs at the loop boundary)
