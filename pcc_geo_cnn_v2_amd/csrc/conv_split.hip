@@ -53,6 +53,10 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
 }
 // only VALU / SALU may cross: memory operations and MFMAs keep their written order (as PCC_PIN_MEM_MFMA in conv_mfma.hip)
 #define PCC_SPLIT_PIN() __builtin_amdgcn_sched_barrier(0x406)
+// timing probes (tools/build_variant.sh): 1 no weight loads in the tap loop, 2 no LDS operand reads in the tap loop, 4 no staging loads
+#ifndef PCC_SPLIT_PROBE
+#define PCC_SPLIT_PROBE 0
+#endif
 
 // Two staging items (2 x 4 input channels of a voxel each): fp32 -> B1 = [dh | dm], B2 = [dl | dh] each.  ONE asm block, because
 // v_dot2c_f32_bf16 is a DOT instruction: a different VALU op that reads its result needs 3 wait states behind it
@@ -226,6 +230,9 @@ conv_k3s1_split_kernel(SplitArgs a) {
                     resv[i][ct] = buf_load4(rres, ok ? off : kOOB, 0);
                 }
             }
+            // the prefetches of the NEXT tap are issued before this tap's MFMAs, not sunk behind them (the scheduler otherwise moves
+            // them to the end of the region, i.e. right in front of their first use: every tap then waits for its LDS reads)
+            PCC_SPLIT_PIN();
             // three MFMAs per (row, cout tile); term outermost: consecutive MFMAs go to different accumulators
 #pragma unroll
             for (int tm = 0; tm < 3; ++tm)
@@ -265,6 +272,191 @@ conv_k3s1_split_kernel(SplitArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second formulation (round 4, late): v_mfma_f32_32x32x16_bf16.  The 16x16x32 kernel above stacks two product terms along K and
+// needs [Wh | Wm], [Wl | Wh] x [dh | dm], [dl | dh] (the h pieces twice on both sides: 8 bytes per element) and re-fetches a 2 KB
+// operand for every 3 MFMAs of 16 cycles.  With M = N = 32 and K = 16 (one product term, 16 input channels) the three pieces of both
+// operands are used as they are -- acc += Wa . db for (a, b) in hh, hm, mh, mm, hl, lh: six MFMAs of 32 cycles per tap, 32 voxels,
+// 32 output channels and 16-channel cin group, the same matrix time -- at 6 bytes per element and 3 KB of operand per side for 192
+// MFMA cycles.  Per wave and tap: A 3 KB x CTW from L2 (32 B/clk/CU), B 3 KB x R rows from LDS (64 B/clk of 256): the launch is
+// bound by the matrix pipe, not by its operand traffic.
+//   lane (n = lane & 31, o = lane >> 5): B = the 8 input channels 8 o .. 8 o + 7 (of the staged 16-channel group) of voxel n of the
+//   row; A = the same 8 input channels of output channel (32 half + n); D: voxel n, output channels 32 half + 8 q + 4 o .. + 3, q = 0..3.
+//   LDS: 112 bytes per voxel: [h: 16 ch x 2 B][m][l][16 B pad]; 28 dwords = 4 x 7 keeps the 16 lanes of a ds_read_b128 group on
+//   distinct bank quads.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int CH, int TZ, int TY, int TXW, int R>
+struct Split32Cfg {
+    static constexpr int NG = CH / 16, NH = CH / 32;   // cin groups of 16, cout halves of 32
+    static constexpr int LPR = 32 / TXW;                // y lines per row of 32 voxels
+    static constexpr int NROW = TZ * TY / LPR;           // rows of the tile
+    static constexpr int NW = NROW / R, NT = NW * 64;
+    static constexpr int LZ = TZ + 2, LY = TY + 2, LX = TXW + 2;
+    static constexpr int VS = 28;                       // dwords per voxel
+    static constexpr int NV = LZ * LY * LX;
+    static constexpr int LDS_BYTES = NV * VS * 4;
+    static constexpr int ITEMS = (NV * 2 + NT - 1) / NT;      // (voxel, channel octet) items per thread: 2 loads, 3 stores each
+    static constexpr int RING = 3;
+    static_assert(NROW % R == 0 && NW == 4 && (TY % (R * LPR) == 0) && 2 * ITEMS <= 27, "bad tile");
+};
+
+template <int CH, int TZ, int TY, int TXW, int R>
+__global__ void __launch_bounds__((Split32Cfg<CH, TZ, TY, TXW, R>::NT), 1) conv_k3s1_split32_kernel(SplitArgs a) {
+    using C = Split32Cfg<CH, TZ, TY, TXW, R>;
+    constexpr int NH = C::NH, NTAP = 27, RING = C::RING, LPR = C::LPR;
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, o = lane >> 5;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = t % a.ntx; t /= a.ntx;
+    const int ty = t % a.nty; t /= a.nty;
+    const int tz = t % a.ntz;
+    const int n = t / a.ntz;
+    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * TXW;
+    const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
+    // wave -> z plane and first row inside it; lane -> voxel of the row
+    constexpr int RPZ = TY / LPR;                        // rows per z plane
+    const int w_z = (wave * R) / RPZ, w_r0 = (wave * R) % RPZ;
+    const int ly0 = w_r0 * LPR + (LPR == 2 ? (nl >> 4) : 0), lx0 = LPR == 2 ? (nl & 15) : nl;
+    const unsigned* lbase = lds + ((w_z * C::LY + ly0) * C::LX + lx0) * C::VS + o * 4;
+    constexpr int ROW_OFF = LPR * C::LX * C::VS;
+
+    f32x16 acc[R][NH];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][h][e] = 0.f;
+
+    const float* inb = a.in + (size_t)n * a.D * a.H * a.W * CH;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)a.D * a.H * a.W * CH * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(C::NG * NTAP * NH) * 3072u);
+    const unsigned wlane = lane * 16;
+    const int q_last = C::NG * NTAP - 1;
+    auto tap_off = [](int kz, int ky, int kx) { return ((kz * C::LY + ky) * C::LX + kx) * C::VS; };
+
+    unsigned soff[C::ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::ITEMS; ++it) {
+        const int item = it * C::NT + tid;
+        const int u = item >> 1, oc = item & 1;
+        const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
+        const int ly = rem / C::LX, lx = rem - ly * C::LX;
+        const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
+        const bool ok = (item < C::NV * 2) & (gz >= 0) & (gz < a.D) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+        soff[it] = ok ? (unsigned)(((gz * a.H + gy) * a.W + gx) * CH + oc * 8) * 4u : kOOB;
+    }
+    auto commit = [&](const f32x4 (&stg)[2 * C::ITEMS]) {
+#pragma unroll
+        for (int it = 0; it < C::ITEMS; ++it) {
+            u32x4 p1, p2, q1, q2;
+            split_items2(p1, p2, q1, q2, stg[2 * it], stg[2 * it + 1]);
+            const int item = it * C::NT + tid;
+            if (item < C::NV * 2) {
+                unsigned* dst = lds + (item >> 1) * C::VS + (item & 1) * 4;
+                *reinterpret_cast<u32x4*>(dst) = (u32x4){p1[0], p1[1], q1[0], q1[1]};          // h of the 8 channels
+                *reinterpret_cast<u32x4*>(dst + 8) = (u32x4){p1[2], p1[3], q1[2], q1[3]};      // m
+                *reinterpret_cast<u32x4*>(dst + 16) = (u32x4){p2[0], p2[1], q2[0], q2[1]};     // l
+            }
+        }
+    };
+
+    f32x4 stg[2 * C::ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::ITEMS; ++it) { stg[2 * it] = buf_load4(rin, soff[it], 0); stg[2 * it + 1] = buf_load4(rin, soff[it], 16); }
+    u32x4 wf[RING][NH][3];
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wf[r][h][p] = buf_load4u(rw, wlane, (unsigned)((min(r, q_last) * NH + h) * 3 + p) * 1024u);
+    commit(stg);
+    __syncthreads();
+
+    const int gzo = oz0 + w_z;
+    const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
+
+#pragma unroll 1
+    for (int g = 0; g < C::NG; ++g) {
+        const unsigned gnext = (unsigned)min(g + 1, C::NG - 1) * 64u;
+        const bool last = g == C::NG - 1;
+        u32x4 b[2][R][3];
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[0][i][p] = *reinterpret_cast<const u32x4*>(lbase + i * ROW_OFF + p * 8);
+#pragma unroll
+        for (int ts = 0; ts < NTAP; ++ts) {
+            {
+                const int q = min(g * NTAP + ts + RING - 1, q_last);
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        if (!(PCC_SPLIT_PROBE & 1)) wf[(ts + RING - 1) % RING][h][p] = buf_load4u(rw, wlane, (unsigned)((q * NH + h) * 3 + p) * 1024u);
+                const int tn = (ts + 1 < NTAP) ? ts + 1 : ts;
+                const int toff = tap_off(tn / 9, (tn / 3) % 3, tn % 3);
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        if (!(PCC_SPLIT_PROBE & 2)) b[(ts + 1) & 1][i][p] = *reinterpret_cast<const u32x4*>(lbase + toff + i * ROW_OFF + p * 8);
+                if (ts < 2 * C::ITEMS && !(PCC_SPLIT_PROBE & 4)) stg[ts] = buf_load4(rin, soff[ts >> 1], gnext + (unsigned)((ts & 1) * 16));
+            }
+            PCC_SPLIT_PIN();         // (prefetches first, see the 16x16x32 kernel)
+            // six product terms; the term outermost so that consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int tm = 0; tm < 6; ++tm) {
+                constexpr int PA[6] = {0, 1, 0, 1, 0, 2}, PB[6] = {0, 1, 1, 0, 2, 0};      // (W piece, d piece): hh mm hm mh hl lh
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) acc[i][h] = mfma32_bf16(wf[ts % RING][h][PA[tm]], b[ts & 1][i][PB[tm]], acc[i][h]);
+            }
+            PCC_SPLIT_PIN();
+        }
+        if (!last) {
+            __syncthreads();
+            commit(stg);
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: lane (voxel nl of the row, octet o) holds output channels 32 h + 8 q + 4 o .. + 3
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(has_res ? a.res + (size_t)n * a.D * a.H * a.W * CH : a.in,
+                                                  has_res ? (unsigned)a.D * a.H * a.W * CH * 4u : 0u);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gy = oy0 + ly0 + i * LPR, gx = ox0 + lx0;
+        if (gzo < a.D && gy < a.H && gx < a.W) {
+            const size_t vox = (((size_t)n * a.D + gzo) * a.H + gy) * a.W + gx;
+            const unsigned rvo = (unsigned)(((gzo * a.H + gy) * a.W + gx) * CH) * 4u;
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = 32 * h + 8 * q + 4 * o;
+                    f32x4 v = {acc[i][h][4 * q], acc[i][h][4 * q + 1], acc[i][h][4 * q + 2], acc[i][h][4 * q + 3]};
+                    if (a.flags & PCC_CONV_BIAS) v += *reinterpret_cast<const f32x4*>(a.bias + c0);
+                    if (a.flags & PCC_CONV_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (has_res) v += buf_load4(rres, rvo + (unsigned)c0 * 4u, 0);
+                    if (a.flags & PCC_CONV_CLIP01) {
+                        v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+                        v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
+                    }
+                    *reinterpret_cast<f32x4*>(a.out + vox * a.ocs + a.oco + c0) = v;
+                }
+        }
+    }
+}
+
 }  // namespace pccsplit
 
 using namespace pccsplit;
@@ -285,7 +477,11 @@ static inline float bf16_f(unsigned short h) {
     memcpy(&v, &b, 4);
     return v;
 }
-size_t pcc_split_packed_floats(int C) { return (size_t)(C / 16) * 27 * (C / 16) * 2 * 64 * 4; }
+// two images: the 16x16x32 kernel's ([g][tap][ct][2 operands][lane][8 bf16]) and, behind it, the 32x32x16 kernel's
+// ([g][tap][cout half][piece h, m, l][lane][8 bf16]: lane (n, o) = output channel 32 half + n, input channels 16 g + 8 o .. + 7)
+static size_t split16_floats(int C) { return (size_t)(C / 16) * 27 * (C / 16) * 2 * 64 * 4; }
+static size_t split32_floats(int C) { return (size_t)(C / 16) * 27 * (C / 32) * 3 * 64 * 4; }
+size_t pcc_split_packed_floats(int C) { return split16_floats(C) + split32_floats(C); }
 void pcc_split_pack(int C, const float* wlog, float* out) {
     unsigned short* o = reinterpret_cast<unsigned short*>(out);
     const int NG = C / 16;
@@ -305,6 +501,22 @@ void pcc_split_pack(int C, const float* wlog, float* out) {
                     unsigned short* a2 = o + (((((size_t)g * 27 + tap) * NG + ct) * 2 + 1) * 64 + lane) * 8;
                     for (int c = 0; c < 4; ++c) { a1[c] = h[c]; a1[4 + c] = m[c]; a2[c] = l[c]; a2[4 + c] = h[c]; }
                 }
+    unsigned short* o3 = o + split16_floats(C) * 2;
+    for (int g = 0; g < NG; ++g)
+        for (int tap = 0; tap < 27; ++tap)
+            for (int half = 0; half < C / 32; ++half)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int c = 0; c < 8; ++c) {
+                        const float x = wlog[((size_t)tap * C + g * 16 + 8 * (lane >> 5) + c) * C + half * 32 + (lane & 31)];
+                        const unsigned short hh = bf16_rn(x);
+                        const float r1 = x - bf16_f(hh);
+                        const unsigned short mm = bf16_rn(r1);
+                        const unsigned short ll = bf16_rn(r1 - bf16_f(mm));
+                        const size_t base = ((((size_t)g * 27 + tap) * (C / 32) + half) * 3) * 64;
+                        o3[((base + 0 * 64 + lane) * 8) + c] = hh;
+                        o3[((base + 1 * 64 + lane) * 8) + c] = mm;
+                        o3[((base + 2 * 64 + lane) * 8) + c] = ll;
+                    }
 }
 
 bool pcc_split_covers(const pcc_conv_desc* d) {
@@ -324,7 +536,10 @@ bool pcc_split_covers(const pcc_conv_desc* d) {
 // the same bits (tests/test_codec_gpu.py::test_blocks_128_cubed_roundtrip_and_layer_parity caught a batch-dependent rule).
 bool pcc_split_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     (void)ctx;
-    return d->Cin == 64;
+    // 64 channels: 128 us against 138 - 146 (Winograd fp32) @16^3 x 32.  32 channels: only on the small grids (38.5 against 45 us @16^3;
+    // at 32^3 the Winograd kernel's 241 us stand against 332: every tile of this kernel pays its staging, split and epilogue
+    // un-overlapped -- at bf16 MFMA rates they are as long as the 27 taps themselves)
+    return d->Cin == 64 || (d->Cin == 32 && d->D <= 16 && (d->W % 32 == 0 || d->W == 16));
 }
 
 int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, const float* residual,
@@ -334,6 +549,27 @@ int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const 
     a.in = in; a.w = w_split; a.bias = bias; a.res = residual; a.out = out;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
     a.flags = d->flags; a.ocs = d->out_cstride ? d->out_cstride : d->Cout; a.oco = d->out_coffset;
+    // Which formulation: measured at batch 32 (tools/bench_one.py) -- 64 -> 64 @16^3: 128 us (16x16x32, tile 2 x 4 x 16) / 134 - 148 (32x32x16);
+    // 32 -> 32 @16^3: 41 / 38.5 us; 32 -> 32 @32^3: 332 / 373 us.  A function of the layer shape only.  PCC_SPLIT_MFMA=16 | 32 overrides (A/B).
+    static const int force = getenv("PCC_SPLIT_MFMA") ? atoi(getenv("PCC_SPLIT_MFMA")) : 0;
+    const bool use32 = force ? force == 32 : d->Cin == 32;
+    if (use32 && (d->W % 32 == 0 || d->W == 16)) {
+        a.w = w_split + split16_floats(d->Cin);
+#define PCC_SPLIT32_LAUNCH(CH, TZ, TY, TXW, R)                                                                     \
+    {                                                                                                              \
+        using C = Split32Cfg<CH, TZ, TY, TXW, R>;                                                                  \
+        a.ntz = (d->D + TZ - 1) / TZ; a.nty = (d->H + TY - 1) / TY; a.ntx = d->W / TXW;                            \
+        const int grid = d->N * a.ntz * a.nty * a.ntx;                                                             \
+        const void* kern = (const void*)conv_k3s1_split32_kernel<CH, TZ, TY, TXW, R>;                              \
+        { const int rc = pcc_enable_big_lds(kern, C::LDS_BYTES); if (rc != PCC_OK) return rc; }                    \
+        hipLaunchKernelGGL((conv_k3s1_split32_kernel<CH, TZ, TY, TXW, R>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, st, a); \
+        PCC_CHECK_HIP(hipGetLastError());                                                                          \
+        return PCC_OK;                                                                                             \
+    }
+        if (d->Cin == 32) { if (d->W % 32 == 0) PCC_SPLIT32_LAUNCH(32, 2, 4, 32, 2) else PCC_SPLIT32_LAUNCH(32, 2, 8, 16, 2) }
+        else { if (d->W % 32 == 0) PCC_SPLIT32_LAUNCH(64, 2, 4, 32, 2) else PCC_SPLIT32_LAUNCH(64, 2, 8, 16, 2) }
+#undef PCC_SPLIT32_LAUNCH
+    }
     // tile 2 x 4 x 16 (69 KB of LDS, two workgroups per CU: the second wave of a SIMD covers the first one's LDS / L2 waits) or
     // 2 x 8 x 16 (115 KB, one workgroup per CU, fewer halo voxels); PCC_SPLIT_TILE=8 selects the large one (A/B)
     static const bool big = getenv("PCC_SPLIT_TILE") != nullptr && atoi(getenv("PCC_SPLIT_TILE")) == 8;
