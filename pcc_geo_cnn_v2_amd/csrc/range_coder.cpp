@@ -92,10 +92,19 @@ class Encoder {
 class Decoder {
   public:
     Decoder(const uint8_t* s, size_t n) : cur_(s), end_(s + n) { read16(); read16(); }
-    // cdf[0..len-1], cdf[0] = 0, cdf[len-1] = 2^precision
-    inline int32_t decode(const int32_t* cdf, int len, int precision) {
+    // cdf[0..len-1], cdf[0] = 0, cdf[len-1] = 2^precision.  `guess` = the most probable symbol of the row (the centre of a Gaussian
+    // table, i.e. the value 0): ~97 % of the y symbols of a trained codec are it, and testing its interval first (two multiplies)
+    // gives the same answer as the bisection over up to 1481 entries (eleven) -- the interval test IS the bisection's exit condition.
+    inline int32_t decode(const int32_t* cdf, int len, int precision, int guess = -1) {
         const uint64_t size = (uint64_t)size_minus1_ + 1;
         const uint64_t offset = (((uint64_t)(uint32_t)(value_ - base_) + 1) << precision) - 1;
+        if (guess >= 0 && guess + 1 < len) {
+            const uint64_t plo = size * (uint64_t)(uint32_t)cdf[guess], phi = size * (uint64_t)(uint32_t)cdf[guess + 1];
+            if (plo <= offset && phi > offset) {
+                narrow((uint32_t)(plo >> precision), (uint32_t)((phi >> precision) - 1));      // = update(cdf[guess], cdf[guess + 1]) with the products at hand
+                return guess;
+            }
+        }
         const int32_t* pv = cdf + 1;
         int n = len - 1;
         do {
@@ -123,8 +132,9 @@ class Decoder {
 
   private:
     inline void update(int32_t lo, int32_t hi, int precision, uint64_t size) {
-        const uint32_t a = (uint32_t)((size * (uint64_t)(uint32_t)lo) >> precision);
-        const uint32_t b = (uint32_t)(((size * (uint64_t)(uint32_t)hi) >> precision) - 1);
+        narrow((uint32_t)((size * (uint64_t)(uint32_t)lo) >> precision), (uint32_t)(((size * (uint64_t)(uint32_t)hi) >> precision) - 1));
+    }
+    inline void narrow(uint32_t a, uint32_t b) {
         base_ += a;
         size_minus1_ = b - a;
         if ((size_minus1_ >> 16) == 0) {
@@ -151,18 +161,23 @@ long encode_stream(const pcc_cdf_table& t, const DataT* data, const IndexT* inde
     Encoder e(out, cap);
     const int ow = t.overflow_width;
     const uint32_t omax = (1u << ow) - 1;
+    // per-row constants side by side (as in decode_stream)
+    struct Row { const int32_t* c; int32_t max_value, offset; };
+    std::vector<Row> rows((size_t)t.rows);
+    for (int r = 0; r < t.rows; ++r) rows[(size_t)r] = Row{t.cdf + (size_t)r * t.cdf_stride, t.cdf_size[r] - 2, t.offset[r]};
     int row_mod = 0;
     for (size_t i = 0; i < n; ++i) {
         int row;
         if (index) row = (int)index[i];
         else { row = row_mod; if (++row_mod == index_mod) row_mod = 0; }
         if ((unsigned)row >= (unsigned)t.rows) return -2;
-        const int32_t max_value = t.cdf_size[row] - 2;
-        int32_t value = (int32_t)data[i] - t.offset[row];
+        const Row& R = rows[(size_t)row];
+        const int32_t max_value = R.max_value;
+        int32_t value = (int32_t)data[i] - R.offset;
         uint32_t overflow = 0;
         if (value < 0) { overflow = (uint32_t)(-2 * (int64_t)value - 1); value = max_value; }
         else if (value >= max_value) { overflow = (uint32_t)(2 * ((int64_t)value - max_value)); value = max_value; }
-        const int32_t* c = t.cdf + (size_t)row * t.cdf_stride;
+        const int32_t* c = R.c;
         e.encode(c[value], c[value + 1], t.precision);
         if (value != max_value) continue;
         int widths = 0;
@@ -186,15 +201,22 @@ int decode_stream(const pcc_cdf_table& t, const uint8_t* str, size_t len, const 
     Decoder d(str, len);
     const int ow = t.overflow_width;
     const uint32_t omax = (1u << ow) - 1;
+    // per-row constants side by side (one cache line per four rows instead of three arrays + a multiply per symbol)
+    struct Row { const int32_t* c; int32_t size, max_value, zero_at, offset; };
+    std::vector<Row> rows((size_t)t.rows);
+    for (int r = 0; r < t.rows; ++r) {
+        const int32_t mv = t.cdf_size[r] - 2, z = -t.offset[r];      // z: table position of the value 0 (the mode of every prior in use)
+        rows[(size_t)r] = Row{t.cdf + (size_t)r * t.cdf_stride, t.cdf_size[r], mv, z >= 0 && z < mv ? z : -1, t.offset[r]};
+    }
     int row_mod = 0;
     for (size_t i = 0; i < n; ++i) {
         int row;
         if (index) row = (int)index[i];
         else { row = row_mod; if (++row_mod == index_mod) row_mod = 0; }
         if ((unsigned)row >= (unsigned)t.rows) return -2;
-        const int32_t max_value = t.cdf_size[row] - 2;
-        const int32_t* c = t.cdf + (size_t)row * t.cdf_stride;
-        int32_t value = d.decode(c, t.cdf_size[row], t.precision);
+        const Row& R = rows[(size_t)row];
+        const int32_t max_value = R.max_value;
+        int32_t value = d.decode(R.c, R.size, t.precision, R.zero_at);
         if (value == max_value) {
             int widths = 0;
             uint32_t val;
@@ -208,7 +230,7 @@ int decode_stream(const pcc_cdf_table& t, const uint8_t* str, size_t len, const 
             if (overflow & 1) value = -value - 1;
             else value += max_value;
         }
-        const int32_t sym = value + t.offset[row];
+        const int32_t sym = value + R.offset;
         out[i] = (OutT)sym;
         if (sizeof(OutT) < 4 && (int32_t)out[i] != sym) return -3;
     }

@@ -42,7 +42,9 @@ def test_split_weight_image_reconstructs_the_fp32_winograd_weights_exactly():
     assert lib.pcc_conv_pack_weights(ctypes.byref(d), w.ctypes.data_as(ctypes.c_void_p), pk.ctypes.data_as(ctypes.c_void_p)) == 0
     G = C // 16
     u32 = pk[27 * C * C:27 * C * C + G * G * 48 * 64 * 4].reshape(G * G, 3, 4, 4, 64, 4)           # [pair][dz][py][px][lane][c]
-    ub = pk[n - G * G * 48 * 2 * 64 * 4:].view(np.uint16).reshape(G * G, 12, 4, 2, 64, 8)            # [pair][slot q][px][operand][lane][8 bf16]
+    # image order: Keras-layout taps | fp32 Winograd U | fp16 fragments (conv_f16.hip: C/16 * 9 * 3 KB for C = 32) | split-bf16 U | conv_split images
+    ub0 = 27 * C * C + G * G * 48 * 64 * 4 + (C // 16) * 9 * 3 * 1024 // 4
+    ub = pk[ub0:ub0 + G * G * 48 * 2 * 64 * 4].view(np.uint16).reshape(G * G, 12, 4, 2, 64, 8)      # [pair][slot q][px][operand][lane][8 bf16]
 
     def f32(h):
         return (h.astype(np.uint32) << 16).view(np.float32)
