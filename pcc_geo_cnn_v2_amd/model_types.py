@@ -337,10 +337,12 @@ class CompressionModel:
         shape."""
         B = len(strings)
         try:
-            ops.range_decode_batch(table, strings, [n] * B, index_list, index_mod, self.coder_threads,
-                                   out=[sym_h[b].numpy().reshape(-1) for b in range(B)])
+            # 2-D fast paths of the wrapper: sym_h (B, ...) is filled in place, the rows come as one 2-D tensor or one shared vector
+            ops.range_decode_batch(table, strings, [n] * B, index_list, index_mod, self.coder_threads, out=sym_h.view(B, -1))
             return sym_h
         except OverflowError:
+            if index_list is not None and not isinstance(index_list, (list, tuple)):     # the list form of the wrapper
+                index_list = [index_list[b] for b in range(B)] if getattr(index_list, 'ndim', 1) >= 2 else [index_list] * B
             wide = ops.range_decode_batch(table, strings, [n] * B, index_list, index_mod, self.coder_threads)
             return torch.from_numpy(np.stack(wide).reshape(sym_h.shape))
 
@@ -810,8 +812,7 @@ class CompressionModelV1(CompressionModel):
             ev.synchronize()
             # a symbol beyond the narrow host type (never seen in practice) shows in the tile maxima: fetch that tensor as int32
             ys_src = stg.ysym if stg.sym_dtype == torch.int32 or int(stg.ytm.max()) <= 32767 else self._to_stream_order(ysym).cpu()
-            ys = ops.range_encode_batch(eb.table, [ys_src[b] for b in range(B)], None if rows is None else [rows] * B, mod,
-                                        self.coder_threads)
+            ys = ops.range_encode_batch(eb.table, ys_src.view(B, -1), rows, mod, self.coder_threads)
             return [(s,) for s in ys]
 
         dbg = [{'y': _np(y[b:b + 1]), 'symbols': _np(ysym[b:b + 1]), 'y_hat': _np(y_hat[b:b + 1]),
@@ -825,7 +826,7 @@ class CompressionModelV1(CompressionModel):
         ysym_h, ysym_release = self._pinned.ring('dec_ysym', yshape, _host_dtypes()[0])
         n = int(np.prod(yshape[1:]))
         rows, mod = self._eb_rows(n, self.num_filters)
-        return dict(ysym=self._range_decode(eb.table, [s[0] for s in strings], n, None if rows is None else [rows] * B, mod, ysym_h),
+        return dict(ysym=self._range_decode(eb.table, [s[0] for s in strings], n, rows, mod, ysym_h),
                     ysym_release=ysym_release)
 
     def _decode_phase_b(self, ctx, st, dhw, debug, thr=None):
@@ -949,10 +950,8 @@ class CompressionModelV2(CompressionModel):
             fits = stg.sym_dtype == torch.int32
             zs_src = stg.zsym if fits or int(stg.ztm.max()) <= 32767 else self._to_stream_order(zsym).cpu()
             ys_src = stg.ysym if fits or int(stg.ytm.max()) <= 32767 else self._to_stream_order(ysym).cpu()
-            zs = ops.range_encode_batch(eb.table, [zs_src[b] for b in range(B)], None if rows is None else [rows] * B, mod,
-                                        self.coder_threads)
-            ys = ops.range_encode_batch(gc.table, [ys_src[b] for b in range(B)], [stg.idx[b] for b in range(B)], 0,
-                                        self.coder_threads)
+            zs = ops.range_encode_batch(eb.table, zs_src.view(B, -1), rows, mod, self.coder_threads)
+            ys = ops.range_encode_batch(gc.table, ys_src.view(B, -1), stg.idx.view(B, -1), 0, self.coder_threads)
             return list(zip(ys, zs))  # strings = (y_string, z_string), model_types.py:389
 
         dbg = [None] * B
@@ -972,8 +971,7 @@ class CompressionModelV2(CompressionModel):
         zsym_h, zsym_release = self._pinned.ring('dec_zsym', zshape, _host_dtypes()[0])
         nz = int(np.prod(zshape[1:]))
         rows, mod = self._eb_rows(nz, F)
-        zpacked = self._symbols_to_device(ctx, self._range_decode(eb.table, [s[1] for s in strings], nz,
-                                                                  None if rows is None else [rows] * B, mod, zsym_h), zsym_release)
+        zpacked = self._symbols_to_device(ctx, self._range_decode(eb.table, [s[1] for s in strings], nz, rows, mod, zsym_h), zsym_release)
         # the 64 scale rows leave in stream order, one byte each
         row_t = _host_dtypes(len(self.scale_table))[1]
         cf = self.data_format == 'channels_first'
@@ -1009,8 +1007,7 @@ class CompressionModelV2(CompressionModel):
         st['ev'].synchronize()
         ysym_h, ysym_release = self._pinned.ring('dec_ysym', idx_h.shape, _host_dtypes()[0])
         n = int(np.prod(idx_h.shape[1:]))
-        packed = self._symbols_to_device(ctx, self._range_decode(gc.table, [s[0] for s in strings], n, [idx_h[b] for b in range(B)], 0,
-                                                                 ysym_h), ysym_release)
+        packed = self._symbols_to_device(ctx, self._range_decode(gc.table, [s[0] for s in strings], n, idx_h.view(B, -1), 0, ysym_h), ysym_release)
         codec = self._codec(ctx)
         if codec is not None:                      # unpack -> dequantise -> synthesis (-> threshold + compaction) in one ABI call
             t = ops.codec_decode_main(ctx, codec, None, dhw, thr, packed=packed, channels_first=self.data_format == 'channels_first')
