@@ -94,24 +94,27 @@ struct SplitArgs {
     int flags, ocs, oco;
 };
 
-template <int CH, int TZ, int TY, int R, int CTW>
+// TXW = 16: an MFMA row = 16 voxels of one y line.  TXW = 8 (the 8^3 grids of the 64-channel layers): a row = 2 y lines of 8 voxels.
+template <int CH, int TZ, int TY, int R, int CTW, int TXW = 16>
 struct SplitCfg {
     static constexpr int NG = CH / 16, NCT = CH / 16;
     static constexpr int NCG = NCT / CTW;               // waves also split the cout tiles
-    static constexpr int NW = TZ * (TY / R) * NCG, NT = NW * 64;
-    static constexpr int LZ = TZ + 2, LY = TY + 2, LX = 18;
+    static constexpr int LPR = 16 / TXW;                // y lines per row
+    static constexpr int NYG = TY / (R * LPR);          // y groups (of R rows) of the tile
+    static constexpr int NW = TZ * NYG * NCG, NT = NW * 64;
+    static constexpr int LZ = TZ + 2, LY = TY + 2, LX = TXW + 2;
     static constexpr int VS = 40;                       // dwords per voxel in LDS: B1 (16) + B2 (16) + 8 pad
     static constexpr int NV = LZ * LY * LX;
     static constexpr int LDS_BYTES = NV * VS * 4;
     static constexpr int ITEMS = ((NV * 4 + NT - 1) / NT + 1) & ~1;      // (voxel, cin quad) items per thread, even: split two at a time
     static constexpr int RING = 3;                      // weight ring depth (taps); 27 % RING == 0
-    static_assert(TY % R == 0 && NCT % CTW == 0 && 27 % RING == 0 && ITEMS <= 26, "bad tile");
+    static_assert(TY % (R * LPR) == 0 && NCT % CTW == 0 && 27 % RING == 0 && ITEMS <= 26 && (TXW == 16 || TXW == 8), "bad tile");
 };
 
-template <int CH, int TZ, int TY, int R, int CTW>
-__global__ void __launch_bounds__((SplitCfg<CH, TZ, TY, R, CTW>::NT), (SplitCfg<CH, TZ, TY, R, CTW>::LDS_BYTES <= 80 * 1024 ? 2 : 1))
+template <int CH, int TZ, int TY, int R, int CTW, int TXW = 16>
+__global__ void __launch_bounds__((SplitCfg<CH, TZ, TY, R, CTW, TXW>::NT), (SplitCfg<CH, TZ, TY, R, CTW, TXW>::LDS_BYTES <= 80 * 1024 ? 2 : 1))
 conv_k3s1_split_kernel(SplitArgs a) {
-    using C = SplitCfg<CH, TZ, TY, R, CTW>;
+    using C = SplitCfg<CH, TZ, TY, R, CTW, TXW>;
     constexpr int NTAP = 27, RING = C::RING;
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,13 +125,13 @@ conv_k3s1_split_kernel(SplitArgs a) {
     const int ty = t % a.nty; t /= a.nty;
     const int tz = t % a.ntz;
     const int n = t / a.ntz;
-    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * TXW;
     const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int ct0 = (wave % C::NCG) * CTW;               // first cout tile of this wave
-    const int w_yg = (wave / C::NCG) % (TY / R), w_z = wave / C::NCG / (TY / R);
-    const int ly0 = w_yg * R, lx0 = v;
+    const int w_yg = (wave / C::NCG) % C::NYG, w_z = wave / C::NCG / C::NYG;
+    const int ly0 = w_yg * R * C::LPR + v / TXW, lx0 = v % TXW;      // row i of the wave: line ly0 + i * LPR
     const unsigned* lbase = lds + ((w_z * C::LY + ly0) * C::LX + lx0) * C::VS + cq * 4;
-    constexpr int ROW_OFF = C::LX * C::VS;
+    constexpr int ROW_OFF = C::LPR * C::LX * C::VS;
 
     f32x4 acc[R][CTW];
 #pragma unroll
@@ -224,7 +227,7 @@ conv_k3s1_split_kernel(SplitArgs a) {
                 if (ts < C::ITEMS) stg[ts] = buf_load4(rin, soff[ts], gnext);
                 if (ts >= RES0 && ts < RES0 + NRES) {
                     const int i = (ts - RES0) / CTW, ct = (ts - RES0) % CTW;
-                    const int gy = oy0 + ly0 + i, gx = ox0 + lx0;
+                    const int gy = oy0 + ly0 + i * C::LPR, gx = ox0 + lx0;
                     const bool ok = last & has_res & (gzo < a.D) & (gy < a.H) & (gx < a.W);
                     const unsigned off = (unsigned)(((gzo * a.H + gy) * a.W + gx) * CH + (ct0 + ct) * 16 + cq * 4) * 4u;
                     resv[i][ct] = buf_load4(rres, ok ? off : kOOB, 0);
@@ -252,7 +255,7 @@ conv_k3s1_split_kernel(SplitArgs a) {
     // ---- epilogue (residual already in registers)
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        const int gy = oy0 + ly0 + i, gx = ox0 + lx0;
+        const int gy = oy0 + ly0 + i * C::LPR, gx = ox0 + lx0;
         if (gzo < a.D && gy < a.H && gx < a.W) {
             const size_t vox = (((size_t)n * a.D + gzo) * a.H + gy) * a.W + gx;
 #pragma unroll
@@ -521,7 +524,7 @@ void pcc_split_pack(int C, const float* wlog, float* out) {
 
 bool pcc_split_covers(const pcc_conv_desc* d) {
     if (!(d->Cin == d->Cout && (d->Cin == 32 || d->Cin == 64) && d->k == 3 && d->stride == 1)) return false;
-    if (d->W % 16) return false;
+    if (d->W % 16 && !(d->Cin == 64 && d->W == 8)) return false;      // (8-wide grids: the 64-channel layers at 8^3)
     const int ocs = d->out_cstride ? d->out_cstride : d->Cout;
     if (ocs % 4 || d->out_coffset % 4) return false;
     return (double)d->D * d->H * d->W * d->Cin * 4.0 < 2147483648.0;        // one image per buffer descriptor
@@ -553,6 +556,17 @@ int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const 
     // 32 -> 32 @16^3: 41 / 38.5 us; 32 -> 32 @32^3: 332 / 373 us.  A function of the layer shape only.  PCC_SPLIT_MFMA=16 | 32 overrides (A/B).
     static const int force = getenv("PCC_SPLIT_MFMA") ? atoi(getenv("PCC_SPLIT_MFMA")) : 0;
     const bool use32 = force ? force == 32 : d->Cin == 32;
+    if (d->W == 8) {
+        // 64 -> 64 on the 8^3 grids (analysis block 3, first / last hyper layers): one z plane x 8 lines x 8 voxels per workgroup =
+        // 8 planes x 32 blocks = 256 workgroups of 4 waves (2 rows x 2 cout tiles each); the fp32 kernel took 36.7 us per launch
+        using C = SplitCfg<64, 1, 8, 2, 2, 8>;
+        a.ntz = d->D; a.nty = (d->H + 7) / 8; a.ntx = 1;
+        const void* kern = (const void*)conv_k3s1_split_kernel<64, 1, 8, 2, 2, 8>;
+        { const int rc = pcc_enable_big_lds(kern, C::LDS_BYTES); if (rc != PCC_OK) return rc; }
+        hipLaunchKernelGGL((conv_k3s1_split_kernel<64, 1, 8, 2, 2, 8>), dim3((unsigned)(d->N * a.ntz * a.nty)), dim3(C::NT), C::LDS_BYTES, st, a);
+        PCC_CHECK_HIP(hipGetLastError());
+        return PCC_OK;
+    }
     if (use32 && (d->W % 32 == 0 || d->W == 16)) {
         a.w = w_split + split16_floats(d->Cin);
 #define PCC_SPLIT32_LAUNCH(CH, TZ, TY, TXW, R)                                                                     \

@@ -439,6 +439,8 @@ SPLIT_CASES = [
     # N, D, H, W, C, tr, bias, relu, res
     (2, 8, 16, 16, 32, False, True, True, True), (1, 6, 8, 32, 32, True, False, False, False), (3, 5, 24, 16, 64, True, True, True, True),
     (1, 16, 16, 16, 64, False, True, False, False), (2, 3, 7, 16, 32, False, True, True, True),
+    # 8-wide grids (64 channels only: the 8^3 layers of analysis block 3 and the hyper transforms): an MFMA row = 2 lines of 8 voxels
+    (2, 8, 8, 8, 64, False, True, True, True), (1, 5, 12, 8, 64, True, True, False, False), (3, 3, 5, 8, 64, True, False, True, True),
 ]
 
 
