@@ -105,6 +105,10 @@ size_t pcc_split_packed_floats(int C);
 void pcc_split_pack(int C, const float* wlog, float* out);
 bool pcc_split_covers(const pcc_conv_desc* d);
 bool pcc_split_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d);
+// Conv3DTranspose k3 stride 2, 64 -> 32 / 64 -> 64, split operands (conv_split.hip); weights = pcc_tr2m_bf16_pack(tr2g-order image)
+bool pcc_tr2_split_covers(const pcc_conv_desc* d);
+int pcc_conv_tr2_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
+                       hipStream_t st);
 int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, const float* residual,
                    float* out, hipStream_t st);
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is set per DEVICE:

@@ -1717,6 +1717,10 @@ PCC_API int pcc_conv_mfma_supported(const pcc_conv_desc* d) {
 }
 
 #define NGROUPS(c) ((c) / 16)
+// stride-2 transposed k3 layers that carry a split-bf16 image behind their two fp32 images: 32 -> 16 (conv_tr2m_bf16.hip), 64 -> 32 and
+// 64 -> 64 (conv_tr2_split_kernel, conv_split.hip)
+static bool tr2_has_split_image(int Cin, int Cout) { return (Cin == 32 && Cout == 16) || (Cin == 64 && (Cout == 32 || Cout == 64)); }
+
 PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
     if (!d) return 0;
     const Plan p = make_plan(d);
@@ -1731,7 +1735,7 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
                        (d->Cin >= 32 ? pcc_split_packed_floats(d->Cin) : 0);                // + the split image of the direct kernel (conv_split.hip)
             return k3 * d->Cin * d->Cout;
         case K_TR2:     // k3: second copy in the order of conv_tr2g_kernel; 32 -> 16: + its split-bf16 image (conv_tr2m_bf16.hip)
-            return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1) + (d->k == 3 && d->Cin == 32 && d->Cout == 16 ? pcc_tr2m_bf16_packed_floats(32, 16) : 0);
+            return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1) + (d->k == 3 && tr2_has_split_image(d->Cin, d->Cout) ? pcc_tr2m_bf16_packed_floats(d->Cin, d->Cout) : 0);
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
         case K_COUT1: return k3 * d->Cin;
         case K_COUT1M: return 2 * 64 * 4;
@@ -1817,7 +1821,7 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                                     pg[((((size_t)g * 27 + sq) * NCT + ct) * 64 + lane) * 4 + j] =
                                         Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
             }
-            if (Cin == 32 && Cout == 16) pcc_tr2m_bf16_pack(Cin, Cout, pg, pg + (size_t)27 * Cin * Cout);
+            if (tr2_has_split_image(Cin, Cout)) pcc_tr2m_bf16_pack(Cin, Cout, pg, pg + (size_t)27 * Cin * Cout);
         }
     } else if (p.kind == K_CIN1) {
         // [kz][ky][kxg][ct][lane] : kx = kxg*4 + (lane>>4) (zero beyond k), cout = ct*16 + (lane&15)
@@ -1909,6 +1913,11 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
         PCC_CASE_FWD(16, 32, 3, 2) PCC_CASE_FWD(32, 64, 3, 2) PCC_CASE_FWD(64, 64, 3, 2)
         PCC_CASE_FWD(32, 32, 3, 2) PCC_CASE_FWD(32, 32, 5, 2)
     } else if (p.kind == K_TR2) {
+        // 64 -> 32 / 64 -> 64: split-bf16 operands on the bf16 MFMA pipe (conv_tr2_split_kernel); shape-only rule, PCC_NO_SPLIT=1 /
+        // PCC_NO_SPLIT_TR2=1: the exact-fp32 kernels below (A/B)
+        if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && getenv("PCC_NO_SPLIT") == nullptr &&
+            getenv("PCC_NO_SPLIT_TR2") == nullptr)
+            return pcc_conv_tr2_split(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, st);
         // z-marching kernel (conv_tr2m.hip) for the 32 -> 16 / 64 -> 32 layers on grids of 16-multiples.  PCC_NO_TR2M=1 keeps the
         // tiled conv_tr2g_kernel, PCC_TR2M=1 takes the marching kernel wherever it is eligible (A/B runs, tests)
         if (getenv("PCC_NO_TR2M") == nullptr && (getenv("PCC_TR2M") != nullptr ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {

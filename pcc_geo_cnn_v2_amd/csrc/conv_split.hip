@@ -24,6 +24,8 @@
 // ahead; the next group's staging loads and the residual rows ride in the tap sections.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -460,6 +462,211 @@ __global__ void __launch_bounds__((Split32Cfg<CH, TZ, TY, TXW, R>::NT), 1) conv_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Conv3DTranspose k3 stride 2 (64 -> 32 @16^3 -> 32^3, 64 -> 64 @8^3 -> 16^3 of /root/reference/src/model_transforms.py:126-137) with
+// split-bf16 operands.  Parity decomposition as in conv_tr2g_kernel (conv_mfma.hip): output voxel 2 b + p takes, per dimension,
+// tap 1 of input b for odd p and taps 0 / 2 of inputs b / b - 1 for even p -- 8 parity classes of 8, 4, 4, 2, 4, 2, 2, 1 taps, 27 in
+// all per input voxel, i.e. the multiply count of a k3 stride-1 layer per INPUT voxel and 8 outputs for it.  Same tile loop as
+// conv_k3s1_split_kernel: per cin group the haloed input tile (halo on the low side only) is staged global -> registers -> split ->
+// LDS once and feeds all 27 taps; the accumulators of all 8 classes stay live across the groups (8 x R x CTW float4), a class is
+// stored right after its last tap in the last group, so the 8 x denser output stream is spread over that group.  Weights: the
+// tr2g-order image [g][class][tap of the class][cout tile] split by pcc_tr2m_bf16_pack, 2 KB per fragment, ring of 3 from L2.
+// fp32 accumulation in a fixed order (cin group -> tap -> three MFMAs): bit-deterministic and independent of the tiling.
+struct Tr2Tap { int cls, dz, dy, dx; bool last; };
+__host__ __device__ constexpr Tr2Tap tr2_tap(int want) {
+    int seq = 0;
+    for (int cls = 0; cls < 8; ++cls) {
+        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+        const int ntap = (pz ? 1 : 2) * (py ? 1 : 2) * (px ? 1 : 2);
+        int t = 0;
+        for (int kz = pz; kz < 3; kz += 2)
+            for (int ky = py; ky < 3; ky += 2)
+                for (int kx = px; kx < 3; kx += 2, ++seq, ++t)
+                    if (seq == want) return Tr2Tap{cls, (pz - kz) / 2, (py - ky) / 2, (px - kx) / 2, t == ntap - 1};
+    }
+    return Tr2Tap{0, 0, 0, 0, false};
+}
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+template <int CIN, int COUT, int TZ, int TY, int R, int CTW, int TXW>
+struct Tr2SplitCfg {
+    static constexpr int NG = CIN / 16, NCT = COUT / 16;
+    static constexpr int NCG = NCT / CTW;
+    static constexpr int LPR = 16 / TXW;
+    static constexpr int NYG = TY / (R * LPR);
+    static constexpr int NW = TZ * NYG * NCG, NT = NW * 64;
+    static constexpr int LZ = TZ + 1, LY = TY + 1, LX = TXW + 1;      // taps reach b - 1 only
+    static constexpr int VS = 40;
+    static constexpr int NV = LZ * LY * LX;
+    static constexpr int LDS_BYTES = NV * VS * 4;
+    static constexpr int ITEMS = ((NV * 4 + NT - 1) / NT + 1) & ~1;
+    static constexpr int RING = 3;
+    static_assert(TY % (R * LPR) == 0 && NCT % CTW == 0 && ITEMS <= 26 && (TXW == 16 || TXW == 8), "bad tile");
+};
+
+template <int CIN, int COUT, int TZ, int TY, int R, int CTW, int TXW>
+__global__ void __launch_bounds__((Tr2SplitCfg<CIN, COUT, TZ, TY, R, CTW, TXW>::NT), 1)      // 8 classes of accumulators: 512 registers per lane
+conv_tr2_split_kernel(SplitArgs a) {
+    using C = Tr2SplitCfg<CIN, COUT, TZ, TY, R, CTW, TXW>;
+    constexpr int NTAP = 27, RING = C::RING;
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int v = lane & 15, cq = lane >> 4;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = t % a.ntx; t /= a.ntx;
+    const int ty = t % a.nty; t /= a.nty;
+    const int tz = t % a.ntz;
+    const int n = t / a.ntz;
+    const int bz0 = tz * TZ, by0 = ty * TY, bx0 = tx * TXW;
+    const int ct0 = (wave % C::NCG) * CTW;
+    const int w_yg = (wave / C::NCG) % C::NYG, w_z = wave / C::NCG / C::NYG;
+    const int ly0 = w_yg * R * C::LPR + v / TXW, lx0 = v % TXW;
+    // B operand base: voxel (w_z + 1, ly0 + 1, lx0 + 1) of the haloed tile (the halo is on the low side), channel quad cq
+    const unsigned* lbase = lds + (((w_z + 1) * C::LY + ly0 + 1) * C::LX + lx0 + 1) * C::VS + cq * 4;
+    constexpr int ROW_OFF = C::LPR * C::LX * C::VS;
+
+    const float* inb = a.in + (size_t)n * a.D * a.H * a.W * CIN;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(inb, (unsigned)a.D * a.H * a.W * CIN * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(C::NG * NTAP * C::NCT) * 2048u);
+    const unsigned wlane = lane * 16;
+    constexpr int q_last = C::NG * NTAP - 1;
+    unsigned soff[C::ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::ITEMS; ++it) {
+        const int item = it * C::NT + tid;
+        const int u = item >> 2, q = item & 3;
+        const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
+        const int ly = rem / C::LX, lx = rem - ly * C::LX;
+        const int gz = bz0 - 1 + lz, gy = by0 - 1 + ly, gx = bx0 - 1 + lx;
+        const bool ok = (item < C::NV * 4) & (gz >= 0) & (gz < a.D) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
+        soff[it] = ok ? (unsigned)(((gz * a.H + gy) * a.W + gx) * CIN + q * 4) * 4u : kOOB;
+    }
+    auto commit = [&](const f32x4 (&stg)[C::ITEMS]) {
+#pragma unroll
+        for (int it = 0; it < C::ITEMS; it += 2) {
+            u32x4 p1, p2, q1, q2;
+            split_items2(p1, p2, q1, q2, stg[it], stg[it + 1]);
+            const int i0 = it * C::NT + tid, i1 = (it + 1) * C::NT + tid;
+            if (i0 < C::NV * 4) {
+                *reinterpret_cast<u32x4*>(lds + (i0 >> 2) * C::VS + (i0 & 3) * 4) = p1;
+                *reinterpret_cast<u32x4*>(lds + (i0 >> 2) * C::VS + 16 + (i0 & 3) * 4) = p2;
+            }
+            if (i1 < C::NV * 4) {
+                *reinterpret_cast<u32x4*>(lds + (i1 >> 2) * C::VS + (i1 & 3) * 4) = q1;
+                *reinterpret_cast<u32x4*>(lds + (i1 >> 2) * C::VS + 16 + (i1 & 3) * 4) = q2;
+            }
+        }
+    };
+
+    f32x4 stg[C::ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::ITEMS; ++it) stg[it] = buf_load4(rin, soff[it], 0);
+    u32x4 wf1[RING][CTW], wf2[RING][CTW];
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            wf1[r][ct] = buf_load4u(rw, wlane, (unsigned)(r * C::NCT + ct0 + ct) * 2048u);
+            wf2[r][ct] = buf_load4u(rw, wlane, (unsigned)(r * C::NCT + ct0 + ct) * 2048u + 1024u);
+        }
+    f32x4 acc[8][R][CTW];
+    {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const f32x4 b4 = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + (ct0 + ct) * 16 + cq * 4) : zero4;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[c][i][ct] = b4;
+        }
+    }
+    commit(stg);
+    __syncthreads();
+
+    // per-row output byte offsets of class (0, 0, 0); a class adds a wave-uniform offset
+    const int OH = 2 * a.H, OW = 2 * a.W;
+    const size_t ovox_n = (size_t)8 * a.D * a.H * a.W;
+    const int gzb = bz0 + w_z, gxb = bx0 + lx0;
+    unsigned ooff[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gyb = by0 + ly0 + i * C::LPR;
+        const bool ok = gzb < a.D && gyb < a.H && gxb < a.W;
+        const unsigned vox = (unsigned)((2 * gzb * OH + 2 * gyb) * OW + 2 * gxb);
+        ooff[i] = ok ? (vox * (unsigned)a.ocs + (unsigned)a.oco + cq * 4) * 4u : kOOB;
+    }
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + (size_t)n * ovox_n * a.ocs, (unsigned)(ovox_n * a.ocs * 4u));
+    const float relu_lo = (a.flags & PCC_CONV_RELU) ? 0.f : -__builtin_inff();
+
+    auto group = [&](auto last_tag, int g) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const unsigned gnext = (unsigned)(g + 1) * 64u;
+        u32x4 b1[2][R], b2[2][R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {       // tap 0: class (0,0,0), (dz, dy, dx) = (0, 0, 0)
+            b1[0][i] = *reinterpret_cast<const u32x4*>(lbase + i * ROW_OFF);
+            b2[0][i] = *reinterpret_cast<const u32x4*>(lbase + i * ROW_OFF + 16);
+        }
+        static_for(std::make_integer_sequence<int, NTAP>{}, [&](auto seq_tag) __attribute__((always_inline)) {
+            constexpr int ts = decltype(seq_tag)::value;
+            constexpr Tr2Tap T = tr2_tap(ts);
+            constexpr Tr2Tap Tn = tr2_tap(ts + 1 < NTAP ? ts + 1 : ts);
+            constexpr int next_off = ((Tn.dz * C::LY + Tn.dy) * C::LX + Tn.dx) * C::VS;
+            constexpr int cls = T.cls;
+            constexpr int WS = ts % RING;      // register slot of this tap's weights
+            {
+                const int q = min(g * NTAP + ts + RING - 1, q_last);
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) {
+                    wf1[(ts + RING - 1) % RING][ct] = buf_load4u(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 2048u);
+                    wf2[(ts + RING - 1) % RING][ct] = buf_load4u(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 2048u + 1024u);
+                }
+                if constexpr (ts + 1 < NTAP) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        b1[(ts + 1) & 1][i] = *reinterpret_cast<const u32x4*>(lbase + next_off + i * ROW_OFF);
+                        b2[(ts + 1) & 1][i] = *reinterpret_cast<const u32x4*>(lbase + next_off + i * ROW_OFF + 16);
+                    }
+                }
+                if constexpr (!LAST && ts < C::ITEMS) stg[ts] = buf_load4(rin, soff[ts], gnext);
+            }
+            PCC_SPLIT_PIN();
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct)
+                        acc[cls][i][ct] = mfma_bf16(tm == 2 ? wf2[WS][ct] : wf1[WS][ct], tm == 1 ? b2[ts & 1][i] : b1[ts & 1][i], acc[cls][i][ct]);
+            PCC_SPLIT_PIN();
+            if constexpr (LAST && T.last) {      // the class is complete: ReLU and stores (the bias is in the accumulators)
+                constexpr int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+                const unsigned coff = (unsigned)(((pz * OH + py) * OW + px) * a.ocs) * 4u;
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        f32x4 o = acc[cls][i][ct];
+                        o = __builtin_elementwise_maximum(o, (f32x4){relu_lo, relu_lo, relu_lo, relu_lo});
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)(ooff[i] + coff + (unsigned)((ct0 + ct) * 16) * 4u), 0, 0);
+                    }
+            }
+        });
+    };
+#pragma unroll 1
+    for (int g = 0; g < C::NG - 1; ++g) {
+        group(std::false_type{}, g);
+        __syncthreads();   // every wave finished reading group g
+        commit(stg);
+        __syncthreads();
+    }
+    group(std::true_type{}, C::NG - 1);
+}
+
 }  // namespace pccsplit
 
 using namespace pccsplit;
@@ -520,6 +727,40 @@ void pcc_split_pack(int C, const float* wlog, float* out) {
                         o3[((base + 1 * 64 + lane) * 8) + c] = mm;
                         o3[((base + 2 * 64 + lane) * 8) + c] = ll;
                     }
+}
+
+// ---- Conv3DTranspose k3 stride 2 with split operands: 64 -> 32 and 64 -> 64 (weights: pcc_tr2m_bf16_pack of the tr2g-order image)
+bool pcc_tr2_split_covers(const pcc_conv_desc* d) {
+    if (!(d->transposed && d->k == 3 && d->stride == 2 && d->Cin == 64 && (d->Cout == 32 || d->Cout == 64))) return false;
+    if (d->flags & ~(PCC_CONV_BIAS | PCC_CONV_RELU)) return false;
+    if (d->W % 16 && d->W != 8) return false;
+    const int ocs = d->out_cstride ? d->out_cstride : d->Cout;
+    if (ocs % 4 || d->out_coffset % 4) return false;
+    return (double)d->D * d->H * d->W * 8.0 * ocs * 4.0 < 2147483648.0 && (double)d->D * d->H * d->W * d->Cin * 4.0 < 2147483648.0;
+}
+
+int pcc_conv_tr2_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
+                       hipStream_t st) {
+    (void)ctx;
+    PCC_REQUIRE(pcc_tr2_split_covers(d), "pcc_conv_tr2_split: shape not covered");
+    SplitArgs a;
+    a.in = in; a.w = w_split; a.bias = bias; a.res = nullptr; a.out = out;
+    a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
+    a.flags = d->flags; a.ocs = d->out_cstride ? d->out_cstride : d->Cout; a.oco = d->out_coffset;
+#define PCC_TR2S_LAUNCH(CO, TZ, TY, R, CTW, TXW)                                                                  \
+    {                                                                                                              \
+        using C = Tr2SplitCfg<64, CO, TZ, TY, R, CTW, TXW>;                                                        \
+        a.ntz = (d->D + TZ - 1) / TZ; a.nty = (d->H + TY - 1) / TY; a.ntx = d->W / TXW;                            \
+        const int grid = d->N * a.ntz * a.nty * a.ntx;                                                             \
+        const void* kern = (const void*)conv_tr2_split_kernel<64, CO, TZ, TY, R, CTW, TXW>;                        \
+        { const int rc = pcc_enable_big_lds(kern, C::LDS_BYTES); if (rc != PCC_OK) return rc; }                    \
+        hipLaunchKernelGGL((conv_tr2_split_kernel<64, CO, TZ, TY, R, CTW, TXW>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, st, a); \
+        PCC_CHECK_HIP(hipGetLastError());                                                                          \
+        return PCC_OK;                                                                                             \
+    }
+    if (d->Cout == 32) { if (d->W == 8) PCC_TR2S_LAUNCH(32, 2, 8, 2, 2, 8) else PCC_TR2S_LAUNCH(32, 2, 8, 4, 2, 16) }
+    else { if (d->W == 8) PCC_TR2S_LAUNCH(64, 1, 8, 2, 2, 8) else PCC_TR2S_LAUNCH(64, 1, 8, 4, 2, 16) }
+#undef PCC_TR2S_LAUNCH
 }
 
 bool pcc_split_covers(const pcc_conv_desc* d) {

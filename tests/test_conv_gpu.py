@@ -207,6 +207,37 @@ def test_winograd_concat_offset(ctx, oracle):
     assert np.all(got[..., :12] == 0) and np.all(got[..., 28:] == 0)
 
 
+TR2_SPLIT_CASES = [
+    # N, D, H, W, cout, bias, relu    (Cin = 64; W = 8: rows of two 8-voxel lines; odd D / H: partial tiles; W = 32: two x tiles)
+    (2, 16, 16, 16, 32, True, True), (1, 5, 7, 16, 32, False, False), (3, 8, 8, 8, 64, True, True), (1, 3, 11, 8, 64, True, False),
+    (2, 4, 8, 32, 32, True, True), (1, 6, 16, 16, 64, False, True), (2, 7, 9, 8, 32, True, True),
+]
+
+
+@pytest.mark.parametrize('case', TR2_SPLIT_CASES)
+def test_stride2_transposed_split_bf16_conv_matches_oracle(ctx, oracle, monkeypatch, case):
+    """conv_tr2_split_kernel (conv_split.hip): Conv3DTranspose k3 stride 2, 64 -> 32 / 64 -> 64 (/root/reference/src/model_transforms.py:78
+    inside :126-137) with three-piece bf16 operands -- against the C oracle at the tolerance of the exact-fp32 kernels; AUTO selects it,
+    PCC_NO_SPLIT_TR2=1 gives the fp32 kernel (other bits, same tolerance); bit-deterministic, independent of batch."""
+    N, D, H, W, cout, bias, relu = case
+    got = _run(ctx, oracle, N, D, H, W, 64, cout, 3, 2, True, bias, relu, False, L.PCC_IMPL_AUTO, seed=53)
+    rng = np.random.default_rng(53)
+    x = torch.from_numpy(rng.standard_normal((N, D, H, W, 64)).astype(np.float32)).to(ctx.device)
+    w = (rng.standard_normal((3, 3, 3, cout, 64)) / np.sqrt(27 * 64)).astype(np.float32)
+    layer = ops.ConvLayer(w, rng.standard_normal(cout).astype(np.float32) if bias else None, 2, True, relu)
+    a = ops.conv3d(ctx, x, layer)
+    assert torch.equal(a, ops.conv3d(ctx, x, layer)) and torch.equal(a[N - 1:], ops.conv3d(ctx, x[N - 1:].contiguous(), layer))
+    monkeypatch.setenv('PCC_NO_SPLIT_TR2', '1')
+    b = ops.conv3d(ctx, x, layer)
+    assert got.shape == (N, 2 * D, 2 * H, 2 * W, cout)
+    assert not torch.equal(a, b), 'AUTO did not select the split kernel'
+    assert (a - b).abs().max().item() <= 2e-5 * (1 + b.abs().max().item())
+    out = torch.zeros((N, 2 * D, 2 * H, 2 * W, cout + 16), device=ctx.device)      # concat offset / channel stride
+    monkeypatch.delenv('PCC_NO_SPLIT_TR2')
+    ops.conv3d(ctx, x, layer, out=out, out_coffset=8)
+    assert torch.equal(out[..., 8:8 + cout], a) and not out[..., :8].any() and not out[..., 8 + cout:].any()
+
+
 TR2M_CASES = [
     # N, D, H, W, cin, cout, bias, relu   (H, W multiples of 16: conv_tr2m.hip; D = 1, odd D, z-split slabs, several x-y tiles)
     (1, 1, 16, 16, 32, 16, True, True), (2, 5, 16, 32, 32, 16, True, False), (1, 9, 32, 16, 64, 32, False, True),
