@@ -1,5 +1,6 @@
 """Randomised parity sweep of the split-bf16 kernels (round 4) against the exact-fp32 direct MFMA kernels: conv16_wino_bf16_kernel
-(16-channel Winograd), conv_k3s1_split_kernel (PCC_IMPL_SPLIT, 32 / 64 channels), conv_tr2m_bf16_kernel (32 -> 16 stride-2 transposed);
+(16-channel Winograd), conv_k3s1_split_kernel (PCC_IMPL_SPLIT, 32 / 64 channels, 16- and 8-wide rows), conv_tr2m_bf16_kernel (32 -> 16 stride-2
+transposed), conv_tr2_split_kernel (64 -> 32 / 64 -> 64 stride-2 transposed);
 odd depths, partial tiles, every epilogue flag, repeat launches bit-identical.   python tools/stress_split.py [seed] [cases]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +11,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = n = 0
 worst = {}
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
-    kind = str(rng.choice(['wino16', 'split', 'tr2m']))
+    kind = str(rng.choice(['wino16', 'split', 'split8', 'tr2m', 'tr2s']))
     N = int(rng.choice([1, 2, 3, 5, 8, 17]))
     D = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 32]))
     bias = bool(rng.integers(0, 2)); relu = bool(rng.integers(0, 2))
@@ -18,6 +19,15 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         cin, cout, s, tr, res, clip = 32, 16, 2, True, False, False
         H = 16 * int(rng.integers(1, 3)); W = 16 * int(rng.integers(1, 3)); D = min(D, 16)
         impl_a, impl_b = L.PCC_IMPL_AUTO, None            # B: the fp32 march (PCC_NO_SPLIT_TR2=1)
+    elif kind == 'tr2s':
+        cin, cout, s, tr, res, clip = 64, int(rng.choice([32, 64])), 2, True, False, False
+        W = int(rng.choice([8, 16, 32])); H = int(rng.choice([1, 3, 8, 9, 16, 17])); D = min(D, 16)
+        impl_a, impl_b = L.PCC_IMPL_AUTO, None            # B: conv_tr2g_kernel / the fp32 march (PCC_NO_SPLIT_TR2=1)
+    elif kind == 'split8':
+        cin = cout = 64
+        s, tr, res, clip = 1, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), False
+        W = 8; H = int(rng.choice([1, 3, 4, 7, 8, 9, 16])); D = min(D, 17)
+        impl_a, impl_b = L.PCC_IMPL_SPLIT, L.PCC_IMPL_MFMA
     else:
         cin = cout = 16 if kind == 'wino16' else int(rng.choice([32, 64]))
         s, tr, res, clip = 1, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0) and kind == 'wino16'

@@ -134,5 +134,10 @@ int main() {
     run<1, SPLIT_DOT>("split dot2c (9 ops)", 1); run<2, SPLIT_DOT>("split dot2c (9 ops)", 1);
     run<1, SPLIT_TRUNC>("split trunc (13 ops)", 1); run<2, SPLIT_TRUNC>("split trunc (13 ops)", 1);
     run<4, ADD>("v_add_f32", 2); run<8, ADD>("v_add_f32", 2); run<8, PKADD>("v_pk_add_f32", 2);
+    // two waves per SIMD: does the second wave fill the issue slots the "slow" classes leave?
+    run<0, ADD>("bf16 mfma only", 2);
+    run<4, MOV>("v_mov_b32", 2); run<8, MOV>("v_mov_b32", 2); run<4, ACCRD>("v_accvgpr_read", 2); run<8, ACCRD>("v_accvgpr_read", 2);
+    run<4, CVTPK>("v_cvt_pk_bf16_f32", 2); run<8, CVTPK>("v_cvt_pk_bf16_f32", 2); run<4, DOT2C>("v_dot2c_f32_bf16", 2); run<8, DOT2C>("v_dot2c_f32_bf16", 2);
+    run<4, PKADD>("v_pk_add_f32", 2); run<2, SPLIT_DOT>("split dot2c (9 ops)", 2); run<2, DS128>("ds_read_b128", 2);
     return 0;
 }
