@@ -28,6 +28,7 @@ pmc cin64 32 16 64 64 3 1 1 res
 pmc tr2m 32 32 32 16 3 2 1
 pmc tr2g 32 16 64 32 3 2 1
 pmc cout1 32 64 16 1 3 1 1
+pmc fwd64_8 32 8 64 64 3 1 0
 # (3) un-profiled bench line for comparison
 cd $R && python bench.py --steps 20 --warmup 3 > $OUT/bench.log 2>&1
 # keep what travels back small

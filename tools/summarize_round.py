@@ -19,12 +19,14 @@ KERNELS = {
                     2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'mfma'),
     'cin32': ('conv16_wino_cin_kernel<true, 2>', 'Conv3DTranspose 32->32 k3 s1 @32^3 + residual, batch 32 (Winograd, cin groups inside the z march)',
               2.0 * B * 32 ** 3 * 27 * 32 * 32, B * 32 ** 3 * 32 * 4 * 3, 'mfma'),
-    'cin64': ('conv16_wino_cin_kernel<true, 4>', 'Conv3DTranspose 64->64 k3 s1 @16^3 + residual, batch 32 (Winograd, cin groups inside the z march, U streamed)',
+    'cin64': ('conv_k3s1_split_kernel<64, 2', 'Conv3DTranspose 64->64 k3 s1 @16^3 + residual, batch 32 (direct, split-bf16 operands, conv_split.hip; round 3: conv16_wino_cin_kernel<4>)',
               2.0 * B * 16 ** 3 * 27 * 64 * 64, B * 16 ** 3 * 64 * 4 * 3, 'mfma'),
-    'tr2m': ('conv_tr2m_kernel', 'Conv3DTranspose 32->16 k3 s2 32^3 -> 64^3, batch 32 (parity-decomposed, z-marching, LDS-resident weights)',
+    'tr2m': ('conv_tr2m_bf16_kernel', 'Conv3DTranspose 32->16 k3 s2 32^3 -> 64^3, batch 32 (parity-decomposed, z-marching, split-bf16 operands, LDS-resident weights)',
              2.0 * B * 32 ** 3 * 27 * 32 * 16, B * (32 ** 3 * 32 + 64 ** 3 * 16) * 4, 'mfma'),
-    'tr2g': ('conv_tr2g_kernel', 'Conv3DTranspose 64->32 k3 s2 16^3 -> 32^3, batch 32 (parity-decomposed, tiled persistent kernel)',
+    'tr2g': ('conv_tr2_split_kernel<64, 32', 'Conv3DTranspose 64->32 k3 s2 16^3 -> 32^3, batch 32 (parity-decomposed tiles, split-bf16 operands; round 3: conv_tr2g_kernel)',
              2.0 * B * 16 ** 3 * 27 * 64 * 32, B * (16 ** 3 * 64 + 32 ** 3 * 32) * 4, 'mfma'),
+    'fwd64_8': ('conv_k3s1_split_kernel<64, 1', 'Conv3D 64->64 k3 s1 @8^3, batch 32 (direct, split-bf16 operands, 8-wide rows; round 3: conv_fwd_kernel)',
+                2.0 * B * 8 ** 3 * 27 * 64 * 64, B * 8 ** 3 * 64 * 4 * 2, 'mfma'),
     'cout1': ('conv_cout1_mfma_kernel', 'Conv3DTranspose 16->1 k3 s1 @64^3, batch 32 (tap-plane MFMA + LDS gather, 32 x 32 columns)',
               2.0 * B * 64 ** 3 * 27 * 16, B * 64 ** 3 * (16 + 1) * 4, 'hbm'),
 }
@@ -50,14 +52,16 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
     fetch = pmc.get('FETCH_SIZE', float('nan')) * 1024 * 2      # KB -> B, x2: gfx950 FETCH_SIZE counts 64 B per 128 B request (MI355X_MICROARCH.md)
     write = pmc.get('WRITE_SIZE', float('nan')) * 1024
     exec_flops = pmc.get('SQ_INSTS_VALU_MFMA_MOPS_F32', float('nan')) * 512
-    if key == 'wino16':     # bf16 MFMAs: v_mfma_f32_16x16x32_bf16 = 16384 flops each (SQ_INSTS_MFMA counts instructions per wave)
+    bf16 = key in ('wino16', 'cin64', 'tr2m', 'tr2g', 'fwd64_8')
+    if bf16:     # bf16 MFMAs: v_mfma_f32_16x16x32_bf16 = 16384 flops each (SQ_INSTS_MFMA counts instructions per wave)
         exec_flops = pmc.get('SQ_INSTS_MFMA', float('nan')) * 16384
     simd_cycles = pmc.get('GRBM_GUI_ACTIVE', float('nan')) / 8 * 1024
     out = {'key': key, 'kernel': frag, 'layer': desc, 'bound': bound,
            'launch_us_unprofiled_min': t_min, 'launch_us_unprofiled_median': t_med,
            'launch_us_in_counter_pass': sum(dur) / max(len(dur), 1),
            'algorithmic_flops_per_launch': alg_flops, 'executed_mfma_flops_per_launch': exec_flops,
-           'executed_tflops': exec_flops / (t_med * 1e-6) / 1e12, 'executed_frac_of_fp32_mfma_peak': exec_flops / (t_med * 1e-6) / 1e12 / PEAK_TF,
+           'mfma_pipe': 'bf16 (split operands: 6x the multiply-adds of the fp32 kernel)' if bf16 else 'fp32',
+           'executed_tflops': exec_flops / (t_med * 1e-6) / 1e12, 'executed_frac_of_pipe_peak': exec_flops / (t_med * 1e-6) / 1e12 / (2500.0 if bf16 else PEAK_TF),
            'algorithmic_tflops': alg_flops / (t_med * 1e-6) / 1e12,
            'mfma_busy_frac_of_simd_cycles': pmc.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) / simd_cycles,
            'mfma_busy_frac_of_wave_cycles': pmc.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) / 4 / pmc.get('SQ_WAVE_CYCLES', float('nan')),
@@ -84,12 +88,12 @@ with open(os.path.join(dst, f'{tag}_bench_kernel_summary.md'), 'w') as f:
     f.write('6 steps of 32 blocks (1 warm-up + 5 timed), c3p @64^3, per (kernel, grid size):\n\n' + summary + '\n')
     f.write('bench.py JSON under the profiler:\n\n```\n' + ''.join(bench_prof) + '```\n\nbench.py JSON without the profiler (same box):\n\n```\n' + ''.join(bench) + '```\n\n')
     f.write('## Counters of the kernels the verdicts name (separate `--pmc` passes on `tools/bench_one.py`, batch 32)\n\n')
-    f.write('| kernel | launch us (median, un-profiled) | executed MFMA GFLOP | executed frac of 157.3 TF | MFMA busy / SIMD cycles | MFMA busy / wave cycles | clock GHz (counter pass) | '
+    f.write('| kernel | launch us (median, un-profiled) | executed MFMA GFLOP | executed frac of the pipe's peak (157.3 TF fp32 / 2500 TF bf16) | MFMA busy / SIMD cycles | MFMA busy / wave cycles | clock GHz (counter pass) | '
             'HBM bytes / algorithmic | algorithmic TB/s (frac of 8) | wait_any | LDS conflict frac |\n|---|---|---|---|---|---|---|---|---|---|---|\n')
     for o in rows:
-        f.write(f"| `{o['kernel']}` {o['layer']} | {o['launch_us_unprofiled_median']:.1f} | {o['executed_mfma_flops_per_launch']/1e9:.2f} | {o['executed_frac_of_fp32_mfma_peak']:.3f} | "
+        f.write(f"| `{o['kernel']}` {o['layer']} | {o['launch_us_unprofiled_median']:.1f} | {o['executed_mfma_flops_per_launch']/1e9:.2f} | {o['executed_frac_of_pipe_peak']:.3f} | "
                 f"{o['mfma_busy_frac_of_simd_cycles']:.3f} | {o['mfma_busy_frac_of_wave_cycles']:.3f} | {o['shader_clock_ghz_in_counter_pass']:.2f} | {o['traffic_over_algorithmic']:.3f} | "
                 f"{o['hbm_tbs_algorithmic']:.2f} ({o['hbm_frac_of_8tbs']:.2f}) | {o['wait_any_frac']:.3f} | {o['lds_bank_conflict_frac_of_lds_cycles']:.3f} |\n")
-    f.write(f'\nFull counter sets: `profiles/{tag}_kernel_counters.json`.  `executed MFMA GFLOP` = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512; HBM bytes = FETCH_SIZE x 2 (gfx950 '
+    f.write(f'\nFull counter sets: `profiles/{tag}_kernel_counters.json`.  `executed MFMA GFLOP` = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 (fp32 kernels) / SQ_INSTS_MFMA x 16384 (split-bf16 kernels: three v_mfma_f32_16x16x32_bf16 per fp32-equivalent product row); HBM bytes = FETCH_SIZE x 2 (gfx950 '
             'correction, MI355X_MICROARCH.md) + WRITE_SIZE.\n')
-print(json.dumps([{k: o[k] for k in ('key', 'launch_us_unprofiled_median', 'executed_frac_of_fp32_mfma_peak', 'mfma_busy_frac_of_simd_cycles', 'traffic_over_algorithmic', 'hbm_frac_of_8tbs')} for o in rows], indent=1))
+print(json.dumps([{k: o[k] for k in ('key', 'launch_us_unprofiled_median', 'executed_frac_of_pipe_peak', 'mfma_busy_frac_of_simd_cycles', 'traffic_over_algorithmic', 'hbm_frac_of_8tbs')} for o in rows], indent=1))
