@@ -240,7 +240,6 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
         static_for(std::make_integer_sequence<int, 27 - T0>{}, [&](auto t_tag) __attribute__((always_inline)) {
             constexpr int t = decltype(t_tag)::value + T0;
             constexpr Tap T = tap_of(t);
-            constexpr Tap Tn = tap_of(t + 1 < 27 ? t + 1 : 0);
             // weight fragment of the next tap (wraps to tap 0 of the next micro-step: loaded after the barrier instead)
             if constexpr (t + 2 < 27) load_w((t + 2 - T0) % 3, tap_of(t + 2).sq);
             constexpr bool open = FIRST && T.opens && T.kz != 0;     // first tap of a class of the odd / even_next set in this plane

@@ -487,7 +487,7 @@ D2Layout d2_layout(int32_t B, size_t nvox, int64_t npts) {
     l.vals1 = o; o += al(pairs * 4);
     l.err = o; o += al(pairs * 8);
     size_t tmp = 0;
-    hipcub::DeviceRadixSort::SortPairs((void*)nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const unsigned*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs((void*)nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const unsigned*)nullptr,
                                        (unsigned*)nullptr, (int)(pairs ? pairs : 1), 0, 48, (hipStream_t)0);
     l.sort_tmp_bytes = tmp;
     l.sort_tmp = o; o += al(tmp + 256);
