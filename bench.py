@@ -60,15 +60,16 @@ def wino_exec_factor(ch, d, batch, num_cu=256):
     return 16.0 / 36.0 * planes / d
 
 
-def c3p_step_flops(res, batch, num_cu=256, winograd=True):
+def c3p_step_flops(res, batch, num_cu=256, winograd=True, split=False):
     """(algorithmic, executed) fp32 MFMA flops of ONE block through compress graph + decompress graph of c3p (the unit of
     SURVEY.md 8d): algorithmic = direct convolution, 2 * MACs as the reference executes them; executed = what the kernels
     issue: the k3 stride-1 layers that csrc/conv_wino.hip takes (conv_mfma.hip dispatch rule: Cin = Cout in {16, 32, 64}, H and W
     multiples of 16) run 16 instead of 36 multiplies per 2x2 outputs and z tap and march
     zlen + 2 input planes per zlen outputs, the first of them with a third of its MFMA rows (zlen = D / z-split, the split that
-    gives every CU a workgroup)."""
+    gives every CU a workgroup).  split = the round-4 dispatch: the 32- / 64-channel layers on grids <= 16^3 are DIRECT convolutions on
+    the bf16 pipe (conv_split.hip: every fp32 product as three bf16 MFMAs), i.e. all 27 taps are executed."""
     def wino_factor(ch, d):
-        if not winograd or d % 16:
+        if not winograd or d % 16 or (split and ch >= 32 and d <= 16):
             return 1.0
         return wino_exec_factor(ch, d, batch, num_cu)
     alg = ex = 0.0
@@ -482,7 +483,7 @@ def main():
             dom_kernel = 'conv16_pers_kernel<2,4,2,20,2> (Conv3DTranspose 16->16 k3 s1 @64^3, 4 launches per step)'
             dom_note = 'direct implicit-GEMM kernel (PCC_NO_WINOGRAD=1): executed == algorithmic flops'
         achieved_exec = exec_flops / (avg_ms * 1e-3) / 1e12
-        alg_step, exec_step = c3p_step_flops(RES, args.chunk, num_cu=ctx.num_cu, winograd=winograd)
+        alg_step, exec_step = c3p_step_flops(RES, args.chunk, num_cu=ctx.num_cu, winograd=winograd, split=split)
         assert abs(alg_step / FLOPS_PER_BLOCK - 1) < 2e-3, (alg_step, FLOPS_PER_BLOCK)       # the layer walk reproduces SURVEY.md 8d
         alg_bytes16 = 3.0 * args.chunk * RES ** 3 * 16 * 2            # fp16 mode: in + residual + out of the timed layer, fp16
         # HBM traffic of the dominant kernel is a PMC measurement of a separate profiled run (profiles/, tools/profile_round.sh): it is
@@ -525,10 +526,16 @@ def main():
                        'device_allocations_in_timed_region': dev_allocs,
                        'cpu_quota_throttled_periods_in_timed_region': None if thr0 is None else thr1 - thr0, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
-                       'mfma_operand_split': (('16-channel k3 stride-1 layers (6 launches per step): fp32 operands as 3 bf16 pieces (8+8+8 significand bits, '
-                                               'round-to-nearest residuals), terms hh hm mh hl mm lh in 3 x v_mfma_f32_16x16x32_bf16 per (z tap, Winograd point), fp32 '
-                                               'accumulate, fixed order (conv_wino_bf16.hip); 32- and 64-channel layers: exact fp32 MFMA (their 96 KB of split weights per '
-                                               'cin group do not fit LDS beside the tile ring)') if split and args.precision == 'fp32' else None),
+                       'mfma_operand_split': (('fp32 operands as 3 bf16 pieces (8+8+8 significand bits, round-to-nearest residuals), product terms hh hm mh hl mm lh in '
+                                               '3 x v_mfma_f32_16x16x32_bf16 per fp32 product row, fp32 accumulate, fixed order.  Per 32-block step (encode + decode): 16-channel '
+                                               'Winograd layers (6 launches, conv_wino_bf16.hip); direct k3 stride-1 64->64 @16^3 (4), 32->32 @16^3 (2), 64->64 @8^3 (5) and '
+                                               'Conv3DTranspose stride 2 64->64 / 64->32 (2 + 2) (conv_split.hip); Conv3DTranspose stride 2 32->16 (2, conv_tr2m_bf16.hip).  '
+                                               'Exact fp32 MFMA: 32->32 @32^3 Winograd (4: its split weights, 96 KB per cin group, do not fit LDS beside the tile ring), the '
+                                               'stride-2 forward layers, the 4^3 grids, first and last layer.  PCC_NO_SPLIT=1: exact fp32 MFMA everywhere')
+                                              if split and args.precision == 'fp32' else None),
+                       'executed_flops_note': ('executed = fp32-equivalent multiply-adds the kernels perform (Winograd layers 16/36 of the taps, direct layers all); with '
+                                               'mfma_operand_split most of them are issued as bf16 MFMAs, so the _executed fraction below is a work figure relative to the fp32 '
+                                               'pipe, not the utilisation of one pipe') if split and args.precision == 'fp32' else None,
                        'bytes_per_block': n_bytes / n_blocks, 'decoded_points_per_block': n_pts / n_blocks,
                        'conv_tflops_whole_step_algorithmic': value * FLOPS_PER_BLOCK / 1e12,
                        # direct-convolution flops / time / peak: the Winograd layers execute 2.1-2.2x fewer multiplies

@@ -319,3 +319,5 @@ def test_bench_flop_model_reproduces_the_survey_and_the_kernel_row_counts():
     assert abs(b.wino_exec_factor(16, 32, 32) - 16 / 36 * (32 + 2 - 4 / 3) / 32) < 1e-12       # two 16-plane slabs
     alg1, ex1 = b.c3p_step_flops(64, 32, winograd=False)
     assert alg1 == alg and ex1 == alg
+    alg2, ex2 = b.c3p_step_flops(64, 32, split=True)          # round 4: the 32- / 64-channel layers on grids <= 16^3 run as direct convolutions
+    assert alg2 == alg and ex < ex2 < alg
