@@ -153,15 +153,21 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
         }
     }
 
-    // ---- plane staging (as conv16_wino_kernel): lane L of chunk c fetches whatever belongs into LDS slot 64c + L
+    // ---- plane staging: lane L of chunk c fetches whatever belongs into the 16-byte LDS unit 64c + L.  Layout of a plane (this kernel's
+    //      own): voxel v = 18 yrow + 9 (x & 1) + (x >> 1) of the haloed 18 x 18 plane (even / odd columns apart: a patch's dx = 0, 2 and
+    //      1, 3 are neighbours), channel quad c4 -> unit 4 v + c4 + v / 36, i.e. one pad unit behind every pair of rows.  A lane's 16 patch
+    //      addresses are then ONE per-lane base + compile-time constants (no swizzle to precompute, no address registers to park), and
+    //      the 16 lanes of a ds_read_b128 group (4 x 4 tiles, one channel quad) still fall on 16 different bank quads:
+    //      byte = 2320 TY + 64 TX + 16 g + const  ->  16 TY + 64 TX (mod 256).
     unsigned rel[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int slot = (wave * 5 + it) * 64 + lane;
-        const int v = slot >> 2, c4 = (slot & 3) ^ ((v >> 1) & 3);
+        const int R = slot / 145, rem = slot - R * 145;
+        const int v = 36 * R + (rem >> 2), c4 = rem & 3;
         const int yrow = v / 18, r = v - yrow * 18, par = r >= 9 ? 1 : 0, col = r - 9 * par, xi = 2 * col + par;
         const int y = Y0 - 1 + yrow, x = X0 - 1 + xi;
-        const bool ok = v < PLANE_VOX && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const bool ok = rem < 144 && v < PLANE_VOX && y >= 0 && y < a.H && x >= 0 && x < a.W;
         rel[it] = ok ? (unsigned)(((y * a.W + x) * a.ics + c4 * 4) * 4) : kOOB;
     }
     auto stage_plane = [&](unsigned plane_off, int z) __attribute__((always_inline)) {
@@ -176,24 +182,21 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
     // ---- per-lane patch read addresses (ring slot 0), tile of this lane
     const int wx = wave & 1, wy = wave >> 1;
     const int TX = 4 * wx + (t & 3), TY = 4 * wy + (t >> 2);
-    unsigned ra[16];
-#pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
-            const int v = 36 * TY + 18 * dy + 9 * (dx & 1) + TX + (dx >> 1);
-            ra[dy * 4 + dx] = (unsigned)(v * 64 + ((g ^ ((v >> 1) & 3)) << 4));
-        }
+    const unsigned pa0 = (unsigned)(64 * (36 * TY + TX) + 16 * (g + TY));       // patch (dy, dx) = (0, 0) of this lane in ring slot 0
+    auto pa_off = [](int dy, int dx) constexpr -> unsigned { return (unsigned)(64 * (18 * dy + 9 * (dx & 1) + (dx >> 1)) + (dy >= 2 ? 16 : 0)); };
     const unsigned ua = (unsigned)(U_BASE + lane * 16);
 
     // ---- epilogue addressing: lane writes couts 4g..4g+3 of the 2x2 voxels of its tile
     const int ox0 = X0 + 2 * TX, oy0 = Y0 + 2 * TY;
-    unsigned ovo[4], rvo[4];
+    // voxel q = (oy, ox) of the 2 x 2 outputs: per-lane offset of voxel 0 + a wave-uniform offset (the buffer instructions' soffset)
+    const unsigned vox0 = (unsigned)(oy0 * a.W + ox0);
+    const unsigned ovo0 = (vox0 * (unsigned)a.ocs + (unsigned)a.oco + 16u * cog + 4u * g) * 4u;
+    const unsigned rvo0 = (vox0 * (unsigned)a.rcs + 16u * cog + 4u * g) * 4u;
+    unsigned oso[4], rso[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const unsigned vox = (unsigned)((oy0 + (q >> 1)) * a.W + ox0 + (q & 1));
-        ovo[q] = (vox * (unsigned)a.ocs + (unsigned)a.oco + 16u * cog + 4u * g) * 4u;
-        rvo[q] = (vox * (unsigned)a.rcs + 16u * cog + 4u * g) * 4u;
+        oso[q] = (unsigned)(((q >> 1) * a.W + (q & 1)) * a.ocs) * 4u;
+        rso[q] = (unsigned)(((q >> 1) * a.W + (q & 1)) * a.rcs) * 4u;
     }
     const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
     const float* res_n = has_res ? a.res + (size_t)n * a.D * HW * a.rcs : a.in;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
     };
     auto load_prow = [&](f32x4 (&P)[4], int dy, unsigned slot_off) __attribute__((always_inline)) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) P[x] = ldsr(ra[dy * 4 + x] + slot_off);
+        for (int x = 0; x < 4; ++x) P[x] = ldsr(pa0 + pa_off(dy, x) + slot_off);
     };
     using R0 = std::integral_constant<int, 0>;
     using R1 = std::integral_constant<int, 1>;
@@ -279,16 +282,12 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
 #pragma unroll
     for (int q = 0; q < 4; ++q) { resv[q] = zero4; ost[q] = zero4; }
 
-    // park the per-lane address constants (see park())
-    unsigned rel_p[ITEMS], ra_p[16], ovo_p[4], rvo_p[4];
+    // park the per-lane address constants (see park()): 9 of them since the plane layout gives every lane ONE patch base
+    unsigned rel_p[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) rel_p[i] = park(rel[i]);
-    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr)smem;       // parked as absolute LDS addresses: no base add at the use
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ra_p[i] = park(lds_base + ra[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { ovo_p[i] = park(ovo[i]); rvo_p[i] = park(rvo[i]); }
-
+    const unsigned pa_p = park((unsigned)(unsigned long long)(lds_ptr)smem + pa0);       // absolute LDS address: no base add at the use
+    const unsigned ovo_p = park(ovo0), rvo_p = park(rvo0);
     unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2 + s0) * HWR;     // plane zo of step s0
     unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2 + s0) * HWO;
     in_pl += (unsigned long long)s0 * HWI;
@@ -330,6 +329,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
             constexpr bool opens = dz == 0 || (MODE == MB_S1O && dz == 1);
             using RS = std::integral_constant<int, (q / 3 + 3) % 4>;        // V row in the split pipeline during this slot
             using STG = std::integral_constant<int, q % 3>;                  // its stage
+            unsigned pa_s = 0, ovo_s = 0, rvo_s = 0;                         // parked addresses this slot needs (one AccVGPR read each)
+            if constexpr (!FIN && (q == 0 || q == 1 || q == 4 || q == 9)) pa_s = unpark_lds(pa_p);
+            if constexpr (q == 8 || q == 11) ovo_s = unpark(ovo_p);
+            if constexpr (q == 0 || q == 3) rvo_s = unpark(rvo_p);
             // ---- F(q): MFMA i, then what runs in its shadow
             static_for<0, 12>([&](auto i_tag) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_tag)::value;
@@ -350,10 +353,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
                 }
                 if constexpr (!FIN) {
                     if constexpr (i < 8 && !(PCC_WB_PROBE & 32)) cvt_task(RS{}, STG{}, i_tag);
-                    if constexpr (q == 0 && i >= 8 && !(PCC_WB_PROBE & 512)) P2[i - 8] = lds_abs(unpark_lds(ra_p[2 * 4 + i - 8]) + slotN);
-                    if constexpr (q == 1 && i >= 8 && !(PCC_WB_PROBE & 512)) P0[i - 8] = lds_abs(unpark_lds(ra_p[0 * 4 + i - 8]) + slotN);
-                    if constexpr (q == 4 && i >= 8 && !(PCC_WB_PROBE & 512)) P1[i - 8] = lds_abs(unpark_lds(ra_p[1 * 4 + i - 8]) + slotN);
-                    if constexpr (q == 9 && i >= 8 && !(PCC_WB_PROBE & 512)) P3[i - 8] = lds_abs(unpark_lds(ra_p[3 * 4 + i - 8]) + slotN);
+                    if constexpr (q == 0 && i >= 8 && !(PCC_WB_PROBE & 512)) P2[i - 8] = lds_abs(pa_s + pa_off(2, i - 8) + slotN);
+                    if constexpr (q == 1 && i >= 8 && !(PCC_WB_PROBE & 512)) P0[i - 8] = lds_abs(pa_s + pa_off(0, i - 8) + slotN);
+                    if constexpr (q == 4 && i >= 8 && !(PCC_WB_PROBE & 512)) P1[i - 8] = lds_abs(pa_s + pa_off(1, i - 8) + slotN);
+                    if constexpr (q == 9 && i >= 8 && !(PCC_WB_PROBE & 512)) P3[i - 8] = lds_abs(pa_s + pa_off(3, i - 8) + slotN);
                     if constexpr (q == 3 && i >= 6 && !(PCC_WB_PROBE & 2))
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(smem + slotW + (wave * 5 + i - 6) * 1024), 16, (int)unpark(rel_p[i - 6]), 0, 0, 0);
                 }
@@ -406,11 +409,11 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
                     ost[v] = o;
                 }
 #pragma unroll
-                for (int v = 2 * oy; v < 2 * oy + 2; ++v) buf_store4(rout, ost[v], unpark(ovo_p[v]), 0);
+                for (int v = 2 * oy; v < 2 * oy + 2; ++v) buf_store4(rout, ost[v], ovo_s, oso[v]);
             }
             if constexpr ((q == 0 || q == 3) && !(PCC_WB_PROBE & 4)) {
 #pragma unroll
-                for (int v = 2 * (q / 3); v < 2 * (q / 3) + 2; ++v) resv[v] = buf_load4(rres, unpark(rvo_p[v]), 0);
+                for (int v = 2 * (q / 3); v < 2 * (q / 3) + 2; ++v) resv[v] = buf_load4(rres, rvo_s, rso[v]);
             }
             // gfx950: a buffer_store_dwordx4 reads its data registers late (conv16_wino_kernel): keep them unwritten for one more slot
             if constexpr (q == 9) { asm volatile("" ::"v"(ost[0])); asm volatile("" ::"v"(ost[1])); }
