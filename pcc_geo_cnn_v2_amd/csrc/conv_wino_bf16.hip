@@ -155,15 +155,17 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
 
     // ---- plane staging: lane L of chunk c fetches whatever belongs into the 16-byte LDS unit 64c + L.  Layout of a plane (this kernel's
     //      own): voxel v = 18 yrow + 9 (x & 1) + (x >> 1) of the haloed 18 x 18 plane (even / odd columns apart: a patch's dx = 0, 2 and
-    //      1, 3 are neighbours), channel quad c4 -> unit 4 v + c4 + v / 36, i.e. one pad unit behind every pair of rows.  A lane's 16 patch
-    //      addresses are then ONE per-lane base + compile-time constants (no swizzle to precompute, no address registers to park), and
-    //      the 16 lanes of a ds_read_b128 group (4 x 4 tiles, one channel quad) still fall on 16 different bank quads:
-    //      byte = 2320 TY + 64 TX + 16 g + const  ->  16 TY + 64 TX (mod 256).
+    //      1, 3 are neighbours), channel quad c4 -> unit 4 v + c4 + 2 (v / 36), i.e. two pad units behind every pair of rows.  A lane's 16
+    //      patch addresses are then ONE per-lane base + compile-time constants (no swizzle to precompute, no address registers to park).
+    //      Bank quads: byte / 16 = 4 TX + g + 2 TY + const (mod 16).  A ds_read_b128 is served in four groups of lanes
+    //      {8k .. 8k+7} + {8k+16 .. 8k+23} (inferred: the XOR-swizzled layout of conv_wino.hip measures 0 conflicts and a one-pad-unit
+    //      version of this layout 0.13 of the LDS cycles, which only this grouping explains) = 4 TX x 2 TY x 2 channel quads: 16
+    //      different bank quads.
     unsigned rel[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int slot = (wave * 5 + it) * 64 + lane;
-        const int R = slot / 145, rem = slot - R * 145;
+        const int R = slot / 146, rem = slot - R * 146;
         const int v = 36 * R + (rem >> 2), c4 = rem & 3;
         const int yrow = v / 18, r = v - yrow * 18, par = r >= 9 ? 1 : 0, col = r - 9 * par, xi = 2 * col + par;
         const int y = Y0 - 1 + yrow, x = X0 - 1 + xi;
@@ -182,8 +184,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
     // ---- per-lane patch read addresses (ring slot 0), tile of this lane
     const int wx = wave & 1, wy = wave >> 1;
     const int TX = 4 * wx + (t & 3), TY = 4 * wy + (t >> 2);
-    const unsigned pa0 = (unsigned)(64 * (36 * TY + TX) + 16 * (g + TY));       // patch (dy, dx) = (0, 0) of this lane in ring slot 0
-    auto pa_off = [](int dy, int dx) constexpr -> unsigned { return (unsigned)(64 * (18 * dy + 9 * (dx & 1) + (dx >> 1)) + (dy >= 2 ? 16 : 0)); };
+    const unsigned pa0 = (unsigned)(64 * (36 * TY + TX) + 16 * (g + 2 * TY));       // patch (dy, dx) = (0, 0) of this lane in ring slot 0
+    auto pa_off = [](int dy, int dx) constexpr -> unsigned { return (unsigned)(64 * (18 * dy + 9 * (dx & 1) + (dx >> 1)) + (dy >= 2 ? 32 : 0)); };
     const unsigned ua = (unsigned)(U_BASE + lane * 16);
 
     // ---- epilogue addressing: lane writes couts 4g..4g+3 of the 2x2 voxels of its tile

@@ -7,6 +7,7 @@ shutil.copy(glob.glob(os.path.join(src, 'trace', '**', 't_kernel_stats.csv'), re
 summary = subprocess.check_output([sys.executable, os.path.join(root, 'tools', 'summarize_trace.py'),
                                    glob.glob(os.path.join(src, 'trace', '**', 't_kernel_trace.csv'), recursive=True)[0], '6', '24'], text=True)
 bench = [l for l in open(os.path.join(src, 'bench.log')) if l.startswith('{"metric"')]
+bench_prof = [l for l in open(os.path.join(src, 'bench_profiled.log')) if l.startswith('{"metric"')]
 pmc, dur = {}, []
 for d in ('fetch', 'write', 'sq', 'mix'):
     for f in glob.glob(os.path.join(src, d, '**', '*counter_collection.csv'), recursive=True):
@@ -36,6 +37,9 @@ json.dump(out, open(os.path.join(dst, f'{tag}_kernel_counters.json'), 'w'), inde
 with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
     f.write(f'# {tag}: fp16 mode, BASELINE.json configs[4] (NOT the headline precision)\n\n`rocprofv3 --kernel-trace --stats -- python bench.py --workload configs4 --steps 5 --warmup 1` '
             '(c3p graph, 128^3 blocks, batch 8, encode+decode), per (kernel, grid size):\n\n' + summary + '\n')
-    f.write('bench.py JSON without the profiler (same box):\n\n```\n' + ''.join(bench) + '```\n\n')
+    f.write('`__amd_rocclr_copyBuffer` rows above: the pinned device<->host copies of the side streams (symbols, CDF-row indexes, decoded point lists).  '
+            'With rocprofv3 attached the runtime executes them as a blit KERNEL on the CUs; without it they go to the SDMA engines '
+            '(`tools/ubench/d2h_copy.hip`), so their share of the kernel time is an artefact of the trace -- the two bench lines below differ by about that share.\n\n')
+    f.write('bench.py JSON under the profiler:\n\n```\n' + ''.join(bench_prof) + '```\n\nbench.py JSON without the profiler (same box):\n\n```\n' + ''.join(bench) + '```\n\n')
     f.write('Dominant kernel of the mode, separate `--pmc` passes on `tools/bench_f16.py 16 8 128 res`:\n\n```\n' + json.dumps(out, indent=1) + '\n```\n')
 print(json.dumps({k: v for k, v in out.items() if k != 'raw_counters'}, indent=1))

@@ -88,7 +88,7 @@ with open(os.path.join(dst, f'{tag}_bench_kernel_summary.md'), 'w') as f:
     f.write('6 steps of 32 blocks (1 warm-up + 5 timed), c3p @64^3, per (kernel, grid size):\n\n' + summary + '\n')
     f.write('bench.py JSON under the profiler:\n\n```\n' + ''.join(bench_prof) + '```\n\nbench.py JSON without the profiler (same box):\n\n```\n' + ''.join(bench) + '```\n\n')
     f.write('## Counters of the kernels the verdicts name (separate `--pmc` passes on `tools/bench_one.py`, batch 32)\n\n')
-    f.write('| kernel | launch us (median, un-profiled) | executed MFMA GFLOP | executed frac of the pipe's peak (157.3 TF fp32 / 2500 TF bf16) | MFMA busy / SIMD cycles | MFMA busy / wave cycles | clock GHz (counter pass) | '
+    f.write('| kernel | launch us (median, un-profiled) | executed MFMA GFLOP | executed frac of the peak of its pipe (157.3 TF fp32 or 2500 TF bf16) | MFMA busy / SIMD cycles | MFMA busy / wave cycles | clock GHz (counter pass) | '
             'HBM bytes / algorithmic | algorithmic TB/s (frac of 8) | wait_any | LDS conflict frac |\n|---|---|---|---|---|---|---|---|---|---|---|\n')
     for o in rows:
         f.write(f"| `{o['kernel']}` {o['layer']} | {o['launch_us_unprofiled_median']:.1f} | {o['executed_mfma_flops_per_launch']/1e9:.2f} | {o['executed_frac_of_pipe_peak']:.3f} | "
