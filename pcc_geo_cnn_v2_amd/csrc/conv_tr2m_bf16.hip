@@ -2,9 +2,13 @@
 //
 // conv_tr2m_kernel<2> (conv_tr2m.hip) ran the first layer of the last SynthesisBlock (/root/reference/src/model_transforms.py:78:
 // 32 -> 16 @32^3 -> 64^3) at 0.67 of the fp32-MFMA peak: 432 fp32 MFMAs per micro-step behind 16 B-operand vectors that are read
-// from LDS once.  That structure is what the operand split wants: the 16 vectors (64 values per lane) are split ONCE per micro-step
-// (8 hazard-safe asm blocks, ~260 VALU ops) and then feed 27 taps x 4 rows x 3 = 324 v_mfma_f32_16x16x32_bf16 of 16 cycles instead
-// of 432 x 32: 5.2 k instead of 13.8 k MFMA cycles per micro-step.  x = h + m + l (three bf16 pieces), terms hh hm mh hl mm lh, fp32
+// from LDS once.  That structure is what the operand split wants: the 16 operand vectors of a micro-step feed 27 taps x 4 rows x 3 =
+// 324 v_mfma_f32_16x16x32_bf16 of 16 cycles instead of 432 x 32: 5.2 k instead of 13.8 k MFMA cycles per micro-step.  The split itself
+// happens ONCE PER TILE ELEMENT (late round 4): the tile of the next micro-step travels global -> registers -> split -> LDS in operand
+// form (160 bytes per voxel as in conv_split.hip: [dh | dm] x 4 channel quads, [dl | dh] x 4, pad), 5 items per thread, and the 16
+// vectors of a lane are 32 plain ds_read_b128.  (First version: the fp32 tile by LDS-direct loads and 8 split blocks per lane and
+// micro-step on the 16 vectors -- the same voxel split up to four times, for its two x and two y offsets; 203 -> 173 us of that launch
+// were the split, a probe build showed.)  x = h + m + l (three bf16 pieces), terms hh hm mh hl mm lh, fp32
 // accumulation in a fixed order, as conv_wino_bf16.hip / conv_split.hip:
 //     acc += [Wh | Wm] . [dh | dm];   acc += [Wh | Wm] . [dl | dh];   acc += [Wl | Wh] . [dh | dm]
 // The split weights of the cout tile (2 x 27 fragments of 2 KB = 108 KB) stay LDS-resident beside the two-tile ring (40 KB); NG = 4
@@ -74,10 +78,12 @@ __device__ __forceinline__ f32x4 acc_read(const f32x4& a) {
 constexpr int NT = 256;
 constexpr int LXY = 17;                                 // tile edge incl. the low-side halo (taps reach b - 1 only)
 constexpr int TILE_SLOTS = LXY * LXY * 4;               // 16-byte slots of one (plane, cin group) tile: 1156
-constexpr int ITEMS = 5;                                // 1 KB chunks per wave (4 x 5 = 20 >= 1156 / 64)
-constexpr int TILE_BYTES = 4 * ITEMS * 1024;            // 20480
-constexpr int W_BASE = 2 * TILE_BYTES;                  // ring of two tiles, then the weights
-constexpr int ROWB = LXY * 64;                          // bytes per tile row
+constexpr int ITEMS = 5;                                // (voxel, channel quad) items per thread: 5 x 256 = 1280 >= 1156
+constexpr int VSB = 160;                                // bytes per voxel of the operand-form tile: B1 x 4 quads, B2 x 4 quads, 32 pad (10 bank quads:
+                                                        // the 8 voxels x 2 quads of a ds_read_b128 lane group fall on 16 different ones)
+constexpr int TILE_BYTES = ITEMS * 64 * VSB;            // 51200: 320 voxel slots (289 used; the items past the tile write zeros into the rest)
+constexpr int W_BASE = TILE_BYTES;                      // one tile, then the weights
+constexpr int ROWB = LXY * VSB;                         // bytes per tile row
 
 struct Tr2mArgs {
     const float* in;
@@ -117,7 +123,6 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v = lane & 15, cq = lane >> 4;
-    auto ldsr = [&](unsigned off) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + off); };
     auto ldsu = [&](unsigned off) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + off); };
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -141,35 +146,44 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
         for (int p = wave; p < NG * 27 * 2; p += 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + W_BASE + p * 1024), 16, lane * 16, ((p >> 1) * a.nct + ct) * 2048 + (p & 1) * 1024, 0, 0);
     }
-    // ---- tile staging: global -> LDS directly.  LDS slot s = 4 * voxel + (channel quad ^ 2 * bit 2 of lx): the swizzle is
-    //      applied on the global side (lane L of chunk c fetches what belongs into slot 64 c + L); OOB lanes write zeros.
+    // ---- tile staging: global -> registers (one micro-step ahead) -> split -> LDS.  Item it of thread tid = (voxel u, channel quad q) =
+    //      ((it * 256 + tid) >> 2, tid & 3); its operands go to u * 160 + q * 16 (B1) and + 64 (B2).  OOB items read zeros.
     unsigned rel[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        const int slot = (wave * ITEMS + it) * 64 + lane;
-        const int u = slot >> 2, ly = u / LXY, lx = u - ly * LXY;
-        const int q = (slot & 3) ^ (((lx >> 2) & 1) << 1);
+        const int item = it * NT + tid;
+        const int u = item >> 2, q = item & 3, ly = u / LXY, lx = u - ly * LXY;
         const int y = Y0 - 1 + ly, x = X0 - 1 + lx;
-        const bool ok = slot < TILE_SLOTS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const bool ok = item < TILE_SLOTS && y >= 0 && y < a.H && x >= 0 && x < a.W;
         rel[it] = ok ? (unsigned)(((y * a.W + x) * CIN + q * 4) * 4) : kOOB;
     }
+    const unsigned cw = (unsigned)((tid >> 2) * VSB + (tid & 3) * 16);       // item it: cw + it * 64 * VSB
+    f32x4 stg[ITEMS];
     // tile of (step sp, cin group cg): `addr` = address of channel 16 cg of input plane zb - 1 + sp (kept incrementally)
-    auto stage_tile = [&](unsigned ring_off, int sp, int cg, unsigned long long addr) __attribute__((always_inline)) {
+    auto fetch_tile = [&](int sp, int cg, unsigned long long addr) __attribute__((always_inline)) {
         const bool ok = (unsigned)(zb - 1 + sp) < (unsigned)a.D && sp < nsteps;
         const __amdgpu_buffer_rsrc_t rp = make_rsrc((const void*)(ok ? addr : (unsigned long long)in_n), ok ? HWI - (unsigned)(64 * cg) : 0u);
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + ring_off + (wave * ITEMS + it) * 1024), 16, (int)rel[it], 0, 0, 0);
+        for (int it = 0; it < ITEMS; ++it) stg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (int)rel[it], 0, 0));
+    };
+    // items j, j + 1 (j = 0, 2) or the single item 4: split and written
+    auto commit2 = [&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value, j1 = j + 1 < ITEMS ? j + 1 : j;
+        u32x4 p1, p2, q1, q2;
+        split_vec2(p1, p2, q1, q2, stg[j], stg[j1]);
+        *reinterpret_cast<u32x4*>(smem + cw + (unsigned)(j * 64 * VSB)) = p1;
+        *reinterpret_cast<u32x4*>(smem + cw + (unsigned)(j * 64 * VSB + 64)) = p2;
+        if constexpr (j1 != j) {
+            *reinterpret_cast<u32x4*>(smem + cw + (unsigned)(j1 * 64 * VSB)) = q1;
+            *reinterpret_cast<u32x4*>(smem + cw + (unsigned)(j1 * 64 * VSB + 64)) = q2;
+        }
     };
 
-    // ---- B operand addresses: lane (v, cq) reads voxel (row, lx = v + 1 + dx) of the tile, its channel quad cq; one base per
-    //      x offset (the swizzle depends on lx), rows / y offsets are immediates.  ba[dxi] points at tile row 4 * wave.
+    // ---- B operand addresses: lane (v, cq) reads voxel (row, lx = v + 1 - dx) of the tile, its channel quad cq; one base per x offset,
+    //      rows / y offsets and the operand (B2 = + 64) are immediates.  ba[dxi] points at tile row 4 * wave.
     unsigned ba[2];
 #pragma unroll
-    for (int dxi = 0; dxi < 2; ++dxi) {
-        const int lx = v + 1 - dxi;
-        ba[dxi] = (unsigned)((4 * wave * LXY + lx) * 64 + ((cq ^ (((lx >> 2) & 1) << 1)) << 4));
-    }
+    for (int dxi = 0; dxi < 2; ++dxi) ba[dxi] = (unsigned)((4 * wave * LXY + v + 1 - dxi) * VSB + cq * 16);
     unsigned wa = (unsigned)(W_BASE + lane * 16);      // + cin group * 54 KB (per micro-step), + tap * 2 KB (immediate)
 
     // ---- epilogue addressing: lane writes couts 4 cq .. 4 cq + 3 (of this cout tile) of output voxel (2 z + pz, 2 y + py, 2 x + px)
@@ -181,25 +195,32 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
     const f32x4 bias_l = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + 16 * ct + 4 * cq) : zero4;
 
     // ---- prologue
+    // (s2, c2, tile_pl): input plane step / cin group / address of the next tile to fetch (wave-uniform)
+    int s2 = 0, c2 = 0;
     unsigned long long tile_pl = (unsigned long long)in_n + (unsigned long long)(long long)(zb - 1) * HWI;     // tile of micro-step 0
-    stage_tile(0, 0, 0, tile_pl);
-    tile_pl += 64;                                    // micro-step 1 = (plane 0, group 1): NG >= 2
-    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+    auto fetch_next = [&]() __attribute__((always_inline)) {
+        fetch_tile(s2, c2, tile_pl);
+        if (++c2 == NG) { c2 = 0; ++s2; tile_pl += HWI - 64 * (NG - 1); } else tile_pl += 64;
+    };
+    fetch_next();
+    commit2(std::integral_constant<int, 0>{}); commit2(std::integral_constant<int, 2>{}); commit2(std::integral_constant<int, 4>{});
+    fetch_next();                                     // raw tile of micro-step 1 waits in registers
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the weights' LDS-direct loads
     __syncthreads();
 
     f32x4 E[2][4][4], O[4][4];                        // accumulators [set][class py * 2 + px][row]
     u32x4 b1[2][2][4], b2[2][2][4];                   // split B operands [dyi][dxi][row] of the current micro-step: [dh | dm], [dl | dh]
     u32x4 wf1[3], wf2[3];                             // weight fragment ring, two taps ahead (a tap is 12 MFMAs = 192 cycles: one tap does not cover an LDS read): [Wh | Wm], [Wl | Wh]
-    // the 16 fp32 vectors of the micro-step are read from LDS and split two at a time (one hazard-safe asm block per pair)
+    // the 16 operand vectors of the micro-step: 32 plain LDS reads
     auto load_b = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int dyi = 0; dyi < 2; ++dyi)
 #pragma unroll
             for (int dxi = 0; dxi < 2; ++dxi)
 #pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                    const f32x4 r0 = ldsr(ba[dxi] + (unsigned)((i + 1 - dyi) * ROWB)), r1 = ldsr(ba[dxi] + (unsigned)((i + 2 - dyi) * ROWB));
-                    split_vec2(b1[dyi][dxi][i], b2[dyi][dxi][i], b1[dyi][dxi][i + 1], b2[dyi][dxi][i + 1], r0, r1);
+                for (int i = 0; i < 4; ++i) {
+                    b1[dyi][dxi][i] = ldsu(ba[dxi] + (unsigned)((i + 1 - dyi) * ROWB));
+                    b2[dyi][dxi][i] = ldsu(ba[dxi] + (unsigned)((i + 1 - dyi) * ROWB + 64));
                 }
     };
     auto load_w = [&](int slot, int sq) __attribute__((always_inline)) {
@@ -211,8 +232,6 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
 
     // wave-uniform march state
     int s = 0, c = 0;                                 // input plane step / cin group of the current micro-step
-    int s1 = 0, c1 = 1;                               // ... of the next micro-step (its tile address: tile_pl)
-    unsigned cur_off = 0;                             // ring slot of the current tile
     unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(2 * (zb - 2)) * PLANE_O;   // planes 2 (z - 1), 2 (z - 1) + 1 of step s = 0
 
     // epilogue item e of a finished plane pair: e < 16: odd set (pz = 1), class e >> 2, row e & 3; else the old even_cur (pz = 0)
@@ -231,8 +250,6 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
         constexpr int PH = decltype(ph_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value, HALO = decltype(halo_tag)::value;
         constexpr int T0 = HALO ? 18 : 0;
-        // tile of the next micro-step -> the other ring slot (its last reader passed the closing barrier of the previous micro-step)
-        stage_tile(cur_off ^ (unsigned)TILE_BYTES, s1, c1, tile_pl);
         // FIRST: the planes finished by the previous input plane leave under the first taps (zero-sized: stores dropped, s < 2)
         const bool prev_ok = s >= 2;
         const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(prev_ok ? out_pl : (unsigned long long)out_n), FIRST && prev_ok ? 2u * PLANE_O : 0u);
@@ -254,6 +271,17 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
 #ifndef PCC_TR2MB_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
 #endif
+            // the tile of the NEXT micro-step (raw, in registers since the previous micro-step) replaces this one in LDS.  Every wave read
+            // its 16 vectors before tap T0: the barrier behind that tap -- where the waves are still close together -- orders the
+            // overwrite behind those reads; split + writes + the request for the tile after next run behind the last tap.  (Measured,
+            // min of bench_one on one box: this placement 182 - 185 us, barrier and blocks all behind the last tap 187 - 190, the three
+            // split blocks spread over taps T0 + 3 .. 5 220 - 228 -- their LDS writes sit between the weight-fragment reads of the
+            // ring, which return in order -- against 202 - 206 for the version that split the 16 vectors per micro-step.)
+            if constexpr (t == T0) __syncthreads();
+            if constexpr (t == 26) {
+                commit2(std::integral_constant<int, 0>{}); commit2(std::integral_constant<int, 2>{}); commit2(std::integral_constant<int, 4>{});
+                fetch_next();
+            }
             if constexpr (FIRST && !HALO) {
                 if constexpr (t < 8) {
                     finish(ph_tag, std::integral_constant<int, 2 * t>{}, rout, ost[t & 1][0]);
@@ -267,18 +295,11 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // the next tile must have landed before the barrier publishes it; the only younger memory operations are the 32 stores
-        // of a FIRST micro-step
-        if (FIRST && !HALO) __builtin_amdgcn_s_waitcnt(0x8F70);      // vmcnt(32)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+        // the operand-form tile of the next micro-step is complete in LDS (this wave's ds_writes: lgkmcnt; the others': barrier)
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt / expcnt untouched (stores and the raw loads stay in flight)
         __syncthreads();
         // ---- advance (wave-uniform) and fetch the operands of the next micro-step
-        cur_off ^= (unsigned)TILE_BYTES;
-        const int d_ring = cur_off ? TILE_BYTES : -TILE_BYTES;
-        ba[0] += (unsigned)d_ring; ba[1] += (unsigned)d_ring;
         if (++c == NG) { c = 0; ++s; out_pl += 2ull * PLANE_O; wa -= (unsigned)((NG - 1) * 27 * 2048); } else wa += 27u * 2048u;
-        tile_pl += 64;
-        if (++c1 == NG) { c1 = 0; ++s1; tile_pl += HWI - 64 * NG; }
         load_b();
         // first weight fragment of the next micro-step (buffer parity follows its first tap: 0, or 18 inside the halo plane)
         if (s == 0) { load_w(0, tap_of(18).sq); load_w(1, tap_of(19).sq); }
