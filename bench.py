@@ -40,7 +40,7 @@ PEAK_FP32_MFMA = 157.3       # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16
 PEAK_BF16_MFMA = 2500.0      # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16x16x32_bf16)
 PEAK_HBM = 8000.0            # GB/s
 # tools/host_budget.sh: cores per rank below which the 1-GPU rate drops by more than 3 %
-HOST_MIN_CORES_PER_RANK = 2        # 16: 6667, 8: 6663, 4: 6629, 3: 6584, 2: 6606, 1: 4149 blocks/s (profiles/r04_host_budget.log; before the coder work of round 4: 3)
+HOST_MIN_CORES_PER_RANK = 3        # late round 4 (4.2 - 4.5 ms steps): 16: 7567 / 7100, 4: 7486 / 7049, 3: 7438 / 7078, 2: 7163 / 6998 blocks/s (profiles/r04_host_budget.log)
 # Synthetic weights (no trained checkpoints exist in the container): Glorot-uniform kernels scaled so that the
 # coded statistics resemble a trained codec at a high-rate point: ~4 % non-zero y symbols (~1.5-2 KB per
 # block), ~5-7 k decoded points per 64^3 block (input: ~5 k points, 2 % occupancy).
