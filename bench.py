@@ -296,6 +296,9 @@ def main():
     if world > 1 or os.environ.get('PCC_BENCH_FORCE_DIST'):     # (the knob exercises the RCCL path on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:      # the knob without a launcher: a one-rank group
+            for k, v in (('RANK', '0'), ('WORLD_SIZE', '1'), ('LOCAL_RANK', '0'), ('MASTER_PORT', '29517')):
+                os.environ.setdefault(k, v)
         if args.dry_run:
             dist.init_process_group('gloo')
         else:
