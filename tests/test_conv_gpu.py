@@ -162,6 +162,51 @@ def test_winograd_at_the_real_launch_geometry_matches_oracle(ctx, oracle, N, ch,
     print(f'winograd {ch}ch @{D}^3 x{N}: max abs err {worst:.2e} ({rel:.2e} of 1 + max|ref|)' + (f'; exact-fp32 MFMA kernel {worst32:.2e}' if ch == 16 else ''))
 
 
+@pytest.mark.parametrize('name,N,D,cin,cout,stride,res', [
+    ('64->64 @16^3 direct split', 32, 16, 64, 64, 1, True), ('64->64 @8^3 direct split, 8-wide rows', 32, 8, 64, 64, 1, False),
+    ('32->32 @16^3 direct split (32x32x16)', 32, 16, 32, 32, 1, True), ('64->32 stride-2 transposed split', 32, 16, 64, 32, 2, False),
+    ('64->64 stride-2 transposed split @8^3', 32, 8, 64, 64, 2, False), ('32->16 stride-2 transposed march', 32, 32, 32, 16, 2, False)])
+def test_split_layers_at_the_bench_launch_geometry_match_oracle(ctx, oracle, name, N, D, cin, cout, stride, res):
+    """The layers of the c3p graph that round 4 moved onto the bf16 pipe besides the 16-channel Winograd ones, AUTO dispatch, at the batch
+    of bench.py (the grids differ from the small parity cases: several rounds of workgroups, XCD remapping, z splits): every block against
+    the oneDNN restatement (pinned to the C oracle on a slab) at the tolerance of the exact-fp32 kernels, bit-equal to a one-block launch,
+    and not the exact-fp32 kernel's bits (the dispatch really takes the split kernel)."""
+    from oracle import torch_oracle as T
+    import os
+    rng = np.random.default_rng(91)
+    w = (rng.standard_normal((3, 3, 3, cout, cin)) / np.sqrt(27 * cin)).astype(np.float32)      # Conv3DTranspose layout
+    b = rng.standard_normal(cout).astype(np.float32)
+    slab = rng.standard_normal((1, 3, 8, 16, cin)).astype(np.float32)
+    a, c = T.conv3d_transpose(slab, w, b, stride, True).numpy(), oracle.conv3d_transpose(slab, w, b, stride, True)
+    assert np.abs(a - c).max() <= 1e-5 * (1 + np.abs(c).max())
+    layer = ops.ConvLayer(w, b, stride, True, True)
+    g = torch.Generator(device='cpu').manual_seed(6)
+    x = torch.randn((N, D, D, D, cin), generator=g)
+    O = D * stride
+    r = torch.randn((N, O, O, O, cout), generator=g) if res else None
+    xd, rd = x.to(ctx.device), None if r is None else r.to(ctx.device)
+    got = ops.conv3d(ctx, xd, layer, residual=rd)
+    one = ops.conv3d(ctx, xd[N - 1:].contiguous(), layer, residual=None if rd is None else rd[N - 1:].contiguous())
+    assert torch.equal(got[N - 1:], one), 'the result depends on the batch / launch geometry'
+    os.environ['PCC_NO_SPLIT'] = '1'
+    try:
+        exact = ops.conv3d(ctx, xd, layer, residual=rd)
+    finally:
+        del os.environ['PCC_NO_SPLIT']
+    assert not torch.equal(got, exact), 'AUTO did not take a split kernel'
+    got, exact = got.cpu(), exact.cpu()
+    worst = worst32 = 0.0
+    for n0 in range(0, N, 4):
+        ref = T.conv3d_transpose(x[n0:n0 + 4], w, b, stride, True)
+        if r is not None:
+            ref = ref + r[n0:n0 + 4]
+        scale = 1 + ref.abs().max().item()
+        worst = max(worst, (got[n0:n0 + 4] - ref).abs().max().item() / scale)
+        worst32 = max(worst32, (exact[n0:n0 + 4] - ref).abs().max().item() / scale)
+    print(f'{name} x{N}: max err / (1 + max|ref|) split {worst:.2e}, exact-fp32 kernel {worst32:.2e}')
+    assert worst <= TOL and worst32 <= TOL
+
+
 def test_split_bf16_winograd_covers_the_fp32_exponent_range_and_is_deterministic(ctx, oracle, monkeypatch):
     """conv_wino_bf16.hip: three bf16 pieces per fp32 operand keep the full fp32 exponent range (unlike fp16 pieces): operands scaled
     by 2^-60 ... 2^+40 give the scaled result of the unscaled launch bit for bit (powers of two commute with every rounding in the
