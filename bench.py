@@ -269,6 +269,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200, help='timed steps (default 200: about one second, so that pipeline fill and drain -- two chunks -- weigh 1 %%)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-ab', action='store_true', help='skip the exact-fp32 A/B (>= 40 steps with the split-bf16 kernels off) that the default run appends')
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[4] (128^3, batch 8, fp16) measurement that the default run appends')
     ap.add_argument('--chunk', type=int, default=CHUNK)
     ap.add_argument('--coder-threads', type=int, default=0,
@@ -355,12 +356,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # Set-up, before the W warm-up steps the contract asks for: PRIME_STEPS passes through the real pipeline.  The first process on a
-    # fresh box pays one-time costs in its first ~10 steps that W = 3..5 does not cover -- first touch of the pinned ring buffers (the
-    # pipeline is three chunks deep plus look-ahead), lazy code-object loads, CPU / GPU clock ramp (measured: arrival gaps of 5.6 and
-    # 8.1 ms among 4.4 ms ones in a --steps 20 --warmup 3 run that was the first process of its box, none in the processes after it).
-    # Untimed; reported as config.setup_priming_steps.
-    PRIME_STEPS = 0 if os.environ.get('PCC_BENCH_NO_PRIME') else 10
+    # Warm-up floor.  The first process on a fresh box pays one-time costs in its first ~10 steps -- first touch of the pinned ring
+    # buffers (the pipeline is three chunks deep plus look-ahead), lazy code-object loads, CPU / GPU clock ramp (measured: arrival gaps
+    # of 5.6 and 8.1 ms among 4.4 ms ones in a --steps 20 --warmup 3 run that was the first process of its box, none in the processes
+    # after it).  The untimed steps are therefore max(W, 10) (round 4 ran 10 + W): with the default W = 10 nothing is added, with a
+    # smaller W the difference runs first as set-up and is reported as config.setup_priming_steps.
+    PRIME_STEPS = 0 if os.environ.get('PCC_BENCH_NO_PRIME') else max(0, 10 - max(args.warmup, 0))
     if PRIME_STEPS:
         run(PRIME_STEPS)
     run(max(args.warmup, 0)) if args.warmup > 0 else None
@@ -429,6 +430,28 @@ def main():
         tot_blocks = n_blocks
     assert n_blocks == args.steps * BATCH
 
+    # Same-process A/B under the same clock: the exact-fp32 MFMA kernels everywhere (the round-3 numerics; PCC_NO_SPLIT=1 selects them
+    # at start-up, here the context's numerics word is switched -- encoder and decoder of a chunk share the context, so they agree).
+    ab_exact = None
+    if args.workload == 'configs1' and args.precision == 'fp32' and world == 1 and not args.no_ab and not (ctx.numerics()[1] & L.PCC_NUM['no_split']):
+        ab_steps = max(40, min(args.steps, 100))
+        with ctx.numerics_override(no_split=True):
+            run(3)
+            ops.profile_select(ctx, L.PCC_NET_SYNTHESIS_PROGRESSIVE_V2, DOM_LAYER, stride=PROFILE_STRIDE)
+            torch.cuda.synchronize(device)
+            a0 = time.perf_counter()
+            nb_ab, _, _ = run(ab_steps)
+            torch.cuda.synchronize(device)
+            a1 = time.perf_counter()
+            k_ab = ops.profile_read(ctx)
+            ops.profile_select(ctx, -1, -1)
+        ab_exact = {'what': 'the same workload in the same process with every split-bf16 kernel off (numerics switch no_split = PCC_NO_SPLIT=1: exact-fp32 '
+                            'v_mfma_f32_16x16x4_f32 everywhere, the round-3 kernels)', 'value': nb_ab / (a1 - a0), 'unit': 'blocks/s', 'steps': ab_steps, 'warmup': 3,
+                    'ms_per_step': 1e3 * (a1 - a0) / ab_steps, 'steady_ms_per_step': steady_ms_per_step(BATCH // args.chunk),
+                    'dominant_kernel': 'conv16_wino_kernel<relu> (exact fp32 MFMA Winograd), synthesis layer 8',
+                    'dominant_avg_launch_ms': float(np.mean(k_ab)) if k_ab else None,
+                    'dominant_median_launch_ms': float(np.median(k_ab)) if k_ab else None, 'launches_timed': len(k_ab)}
+
     # BASELINE.json configs[4] (c6 = the c3p graph, 128^3 blocks, batch 8, fp16 MFMA) measured in the SAME process, so that the
     # driver's one `bench.py --gpus 1` run times it too.  A separate, labelled object: never the headline value.
     secondary = None
@@ -470,8 +493,9 @@ def main():
         flops_launch = 2.0 * args.chunk * RES ** 3 * 27 * 16 * 16     # algorithmic flops of one dominant launch
         avg_ms = float(np.mean(kern_ms)) if kern_ms else float('nan')
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12
-        winograd = os.environ.get('PCC_NO_WINOGRAD') is None
-        split = winograd and os.environ.get('PCC_NO_SPLIT') is None      # 16-channel layers on the bf16 MFMA pipe (conv_wino_bf16.hip)
+        num_sw = ctx.numerics()[1]
+        winograd = not (num_sw & L.PCC_NUM['no_winograd'])
+        split = winograd and not (num_sw & L.PCC_NUM['no_split'])      # 16-channel layers on the bf16 MFMA pipe (conv_wino_bf16.hip)
         alg_bytes_launch = 3.0 * args.chunk * RES ** 3 * 16 * 4           # input + residual + output of the timed layer, fp32
         if winograd:
             # F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap); padding planes skipped
@@ -503,8 +527,12 @@ def main():
         if split:
             dom_roofline = {'bound': 'hbm', 'kernel': dom_kernel, 'achieved': alg_bytes_launch / (avg_ms * 1e-3) / 1e9, 'peak': PEAK_HBM, 'unit': 'GB/s',
                             'frac': alg_bytes_launch / (avg_ms * 1e-3) / 1e9 / PEAK_HBM, 'traffic': None, 'traffic_profiled': traffic_profiled,
-                            'algorithmic_bytes_per_launch': alg_bytes_launch, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms),
-                            'timed_launch_stride': PROFILE_STRIDE,
+                            'algorithmic_bytes_per_launch': alg_bytes_launch, 'avg_launch_ms': avg_ms, 'median_launch_ms': float(np.median(kern_ms)) if kern_ms else None,
+                            'launches_timed': len(kern_ms), 'timed_launch_stride': PROFILE_STRIDE,
+                            'frac_definition': ('HBM roof: algorithmic bytes of one launch (fp32 input + residual + output = 3 x 32 x 64^3 x 16 x 4 B) / mean HIP-event '
+                                                'launch time / 8 TB/s.  NOT comparable with rounds 1-3, whose frac was executed fp32-MFMA flops / 157.3 TFLOP/s '
+                                                '(that figure is kept as mfma.fp32_equivalent_over_fp32_mfma_peak; the bf16-pipe utilisation is '
+                                                'mfma.frac_of_bf16_mfma_peak)'),
                             'mfma': {'executed_bf16_flops_per_launch': 6.0 * exec_flops, 'executed_bf16_tflops': 6.0 * achieved_exec,
                                      'frac_of_bf16_mfma_peak': 6.0 * achieved_exec / PEAK_BF16_MFMA,
                                      'fp32_equivalent_flops_per_launch': exec_flops, 'fp32_equivalent_tflops': achieved_exec,
@@ -518,6 +546,7 @@ def main():
                             'achieved': achieved_exec, 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s', 'frac': achieved_exec / PEAK_FP32_MFMA,
                             'traffic': None, 'traffic_profiled': traffic_profiled if winograd else None, 'algorithmic_bytes_per_launch': alg_bytes_launch,
                             'executed_flops_per_launch': exec_flops, 'avg_launch_ms': avg_ms, 'launches_timed': len(kern_ms), 'timed_launch_stride': PROFILE_STRIDE,
+                            'frac_definition': 'fp32 MFMA roof: executed v_mfma_f32_16x16x4_f32 flops of one launch / mean HIP-event launch time / 157.3 TFLOP/s',
                             'algorithmic_flops_per_launch': flops_launch, 'algorithmic_tflops': achieved,
                             'algorithmic_speedup_vs_direct_roof': achieved / PEAK_FP32_MFMA,
                             'note': dom_note}
@@ -534,7 +563,7 @@ def main():
                        'host_cores_busy_per_rank': round(host_cores_busy, 2), 'host_cpu_quota_cores': ops.usable_cores(),
                        'host_cores_per_rank': cores_per_rank, 'host_bound': bool(host_cores_busy >= 0.9 * cores_per_rank),
                        'host_min_cores_per_rank_measured': HOST_MIN_CORES_PER_RANK,
-                       'setup_priming_steps': PRIME_STEPS,
+                       'setup_priming_steps': PRIME_STEPS, 'codec_numerics': ctx.numerics_tag(args.precision),
                        'device_allocations_in_timed_region': dev_allocs,
                        'cpu_quota_throttled_periods_in_timed_region': None if thr0 is None else thr1 - thr0, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
@@ -566,6 +595,7 @@ def main():
                                   'output / HIP-event launch time; HBM3E peak 8 TB/s, ~6.3 TB/s achievable (MI355X_MICROARCH.md)'}
                          if args.precision == 'fp16' else dom_roofline),
         }
+        out['ab_exact_fp32'] = ab_exact
         out['secondary'] = secondary
         out['multi_gpu'] = multi
         if world == 1 and not args.no_cpu_baseline and args.workload == 'configs1':

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PCC_ABI_VERSION 3
+#define PCC_ABI_VERSION 4
 
 /* ---- errors / context ------------------------------------------------------------------ */
 #define PCC_OK 0
@@ -47,6 +47,36 @@ int pcc_ctx_create(int device, pcc_ctx** out);
 int pcc_ctx_destroy(pcc_ctx* ctx);
 /* Number of compute units of the context's device (256 on MI355X); <0 on error. */
 int pcc_ctx_num_cu(pcc_ctx* ctx);
+
+/* ---- codec numerics: which kernel family computes a layer ---------------------------------
+ * Encoder and decoder must produce the SAME bits for sigma-hat (it selects the entropy coder's rows: a single flipped scale index
+ * desynchronises the range decoder -- the reason for the reference's --debug retries, src/decompress_octree.py:84-101).  Every
+ * kernel here is bit-deterministic, but two kernel families (exact-fp32 MFMA, split-bf16 MFMA, Winograd, direct ...) give different
+ * round-off.  What selects the family is therefore STATE OF THE CONTEXT, read ONCE from the environment in pcc_ctx_create (the
+ * PCC_* variables named below) and changeable only through pcc_ctx_set_numerics -- never per call -- and it is recorded beside
+ * every stream the CLIs write (gzip header comment, model_syntax.write_tagged_gzip) together with PCC_KERNEL_FAMILY, which is bumped whenever
+ * a default kernel's summation order changes.  The decoder refuses a stream written under another tag. */
+#define PCC_KERNEL_FAMILY 5
+#define PCC_NUM_NO_SPLIT 0x1         /* PCC_NO_SPLIT=1: every split-bf16 kernel off (exact-fp32 MFMA everywhere)              */
+#define PCC_NUM_NO_SPLIT_DIRECT 0x2  /* PCC_NO_SPLIT_DIRECT=1: the direct 32- / 64-channel split kernels off                  */
+#define PCC_NUM_NO_SPLIT_TR2 0x4     /* PCC_NO_SPLIT_TR2=1: the stride-2 transposed split kernels off                         */
+#define PCC_NUM_NO_WINOGRAD 0x8      /* PCC_NO_WINOGRAD=1: direct kernels instead of Winograd                                 */
+#define PCC_NUM_NO_WINOGRAD32 0x10   /* PCC_NO_WINOGRAD32=1                                                                   */
+#define PCC_NUM_NO_WINOGRAD64 0x20   /* PCC_NO_WINOGRAD64=1                                                                   */
+#define PCC_NUM_WINO_PER_GROUP 0x40  /* PCC_WINO_PER_GROUP=1: one Winograd launch per cin group                               */
+#define PCC_NUM_NO_TR2M 0x80         /* PCC_NO_TR2M=1: tiled stride-2 transposed kernels instead of the z march               */
+#define PCC_NUM_TR2M 0x100           /* PCC_TR2M=1: the z march wherever it is eligible                                       */
+#define PCC_NUM_TR2_OLD 0x200        /* PCC_TR2_OLD=1: per-tile conv_tr2_kernel                                               */
+#define PCC_NUM_SPLIT_MFMA16 0x400   /* PCC_SPLIT_MFMA=16: 16x16x32 formulation of the direct split kernel                    */
+#define PCC_NUM_SPLIT_MFMA32 0x800   /* PCC_SPLIT_MFMA=32: 32x32x16 formulation                                               */
+#define PCC_NUM_SPLIT_TILE8 0x1000   /* PCC_SPLIT_TILE=8                                                                      */
+#define PCC_NUM_P16 0x2000           /* PCC_P16=1: one 8-wave workgroup per CU in the direct 16 -> 16 kernel                  */
+#define PCC_NUM_NO_SPLIT32M 0x4000   /* PCC_NO_SPLIT32M=1: 32 -> 32 on grids > 16^3 stays on the exact-fp32 Winograd kernel  */
+#define PCC_NUM_COUT1_T16 0x8000     /* PCC_COUT1_T16=1: 16 x 16 columns in the 16 -> 1 last layer (same bits as 32 x 32: tested)  */
+/* family = PCC_KERNEL_FAMILY of this build, switches = OR of PCC_NUM_* in effect on this context */
+int pcc_ctx_get_numerics(pcc_ctx* ctx, uint32_t* family, uint32_t* switches);
+/* Replace the switches (tests, A/B runs).  Not to be called between an encode and the decode of its stream. */
+int pcc_ctx_set_numerics(pcc_ctx* ctx, uint32_t switches);
 
 /* ---- 3-D convolution / transposed convolution -------------------------------------------
  * Replaces the TF ops behind keras Conv3D / Conv3DTranspose (+BiasAdd, Relu, AddV2) at

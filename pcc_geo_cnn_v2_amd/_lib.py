@@ -16,7 +16,7 @@ PCC_IMPL_AUTO, PCC_IMPL_GENERIC, PCC_IMPL_MFMA, PCC_IMPL_WINOGRAD, PCC_IMPL_SPLI
 PCC_ROUND_FLOOR_HALF, PCC_ROUND_HALF_EVEN = 0, 1
 
 EXPORTS = [
-    'pcc_abi_version', 'pcc_last_error', 'pcc_ctx_create', 'pcc_ctx_destroy', 'pcc_ctx_num_cu',
+    'pcc_abi_version', 'pcc_last_error', 'pcc_ctx_create', 'pcc_ctx_destroy', 'pcc_ctx_num_cu', 'pcc_ctx_get_numerics', 'pcc_ctx_set_numerics',
     'pcc_conv_out_dims', 'pcc_conv_mfma_supported', 'pcc_conv_packed_floats', 'pcc_conv_pack_weights',
     'pcc_conv3d', 'pcc_quantize', 'pcc_dequantize', 'pcc_scale_to_index', 'pcc_threshold_compact',
     'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
@@ -29,7 +29,11 @@ EXPORTS = [
     'pcc_codec_workspace_bytes', 'pcc_codec_encode', 'pcc_codec_decode_hyper', 'pcc_codec_decode_main',
     'pcc_profile_select', 'pcc_profile_read',
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
+# include/pcc_geo.h "codec numerics": switches that select the kernel family of a layer (state of the context, recorded beside every stream)
+PCC_NUM = dict(no_split=0x1, no_split_direct=0x2, no_split_tr2=0x4, no_winograd=0x8, no_winograd32=0x10, no_winograd64=0x20,
+               wino_per_group=0x40, no_tr2m=0x80, tr2m=0x100, tr2_old=0x200, split_mfma16=0x400, split_mfma32=0x800, split_tile8=0x1000,
+               p16=0x2000, no_split32m=0x4000, cout1_t16=0x8000)
 PCC_ERR_ARG, PCC_ERR_HIP, PCC_ERR_NOGPU, PCC_ERR_SPACE, PCC_ERR_CORRUPT = -1, -2, -3, -4, -5      # include/pcc_geo.h
 (PCC_NET_ANALYSIS_V1, PCC_NET_SYNTHESIS_V1, PCC_NET_ANALYSIS_V2, PCC_NET_SYNTHESIS_V2, PCC_NET_ANALYSIS_PROGRESSIVE_V2,
  PCC_NET_SYNTHESIS_PROGRESSIVE_V2, PCC_NET_HYPER_ANALYSIS, PCC_NET_HYPER_SYNTHESIS) = range(8)
@@ -84,6 +88,8 @@ def lib():
     L.pcc_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.pcc_ctx_destroy.argtypes = [vp]
     L.pcc_ctx_num_cu.argtypes = [vp]
+    L.pcc_ctx_get_numerics.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.pcc_ctx_set_numerics.argtypes = [vp, C.c_uint32]
     L.pcc_conv_out_dims.argtypes = [C.POINTER(ConvDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.pcc_conv_mfma_supported.argtypes = [C.POINTER(ConvDesc)]
     L.pcc_conv_packed_floats.argtypes = [C.POINTER(ConvDesc)]

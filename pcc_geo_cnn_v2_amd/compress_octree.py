@@ -10,7 +10,6 @@ checkpoint; `--batch_size` (blocks resident per GPU pass) is new.  Under
 the files.  `--num_filters` is accepted and ignored, like in the reference.
 """
 import argparse
-import gzip
 import json
 import logging
 import os
@@ -112,14 +111,13 @@ def _block_grid(resolution, level, data_format):
 def _write_rate_point(target, decoded_path, binstr, streams, info, args, blocks, debug_t_list):
     """The files of one rate point: <target> (gzip'd container), <target>.enc.metric.json, optionally the decoded cloud and the
     --debug dumps (/root/reference/src/compress_octree.py:109-125 lists them)."""
-    from .model_syntax import save_compressed_file
+    from .model_syntax import save_compressed_file, write_tagged_gzip
     from .utils import pc_io
     folder = os.path.dirname(target)
     if folder:
         os.makedirs(folder, exist_ok=True)
     payload = save_compressed_file(binstr, streams, args.resolution, args.octree_level, strict=True)
-    with gzip.open(target, 'wb') as fh:
-        fh.write(payload)
+    write_tagged_gzip(target, payload, info['numerics_tag'])      # = gzip.open(target, 'wb').write(payload) + the tag in the member header
     with open(target + '.enc.metric.json', 'w') as fh:
         json.dump({name: float(val) for name, val in info['metrics'].items()}, fh, sort_keys=True, indent=4)
     if decoded_path is not None:
@@ -168,6 +166,7 @@ def compress(args):
             if len(streams) != len(cloud.targets):
                 raise AssertionError(f'{len(streams)} rate points for {len(cloud.targets)} output files')
             for n, target in enumerate(cloud.targets):
+                infos[n]['numerics_tag'] = sess.numerics_tag(args.precision)
                 _write_rate_point(target, None if cloud.decoded is None else cloud.decoded[n], binstr, streams[n], infos[n], args, blocks, debug_t_list)
             logger.info(f'Finished {cloud.source} to {", ".join(cloud.targets)} with {len(blocks)} blocks')
     if world > 1:

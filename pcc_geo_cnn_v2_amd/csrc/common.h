@@ -16,8 +16,13 @@ struct pcc_ctx {
     // (conv_f16.hip).  One tensor per context: launches that use it must be ordered on one stream.
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    // PCC_NUM_* switches in effect (include/pcc_geo.h, "codec numerics"): read from the environment ONCE, in pcc_ctx_create;
+    // every dispatch decision that changes the bits of a layer tests this word, never getenv
+    uint32_t numerics = 0;
+    bool num(uint32_t bit) const { return (numerics & bit) != 0; }
 };
 int pcc_ctx_scratch(pcc_ctx* ctx, size_t bytes, void** ptr);
+uint32_t pcc_numerics_from_env();
 void pcc_profile_free(pcc_ctx* ctx);
 
 void pcc_set_error(const char* fmt, ...);

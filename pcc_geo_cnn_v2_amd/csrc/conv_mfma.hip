@@ -1559,7 +1559,7 @@ int launch(KernelT kern, int nt, int lds_bytes, int tiles, const ConvArgs& a, hi
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 template <int CIN, int COUT, int KS, int S>
-int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
+int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu, uint32_t numerics) {
     // tile shapes per row width: (TX, TZ, TY, TXT, R)
 #define PCC_FWD(TX, TZ, TY, TXT, R) PCC_FWDC(TX, TZ, TY, TXT, R, (COUT / 16))
 #define PCC_FWDC(TX, TZ, TY, TXT, R, CTW)                                                               \
@@ -1594,8 +1594,7 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
         const int grid = ntiles < num_cu * WPC ? ntiles : num_cu * WPC;                                 \
         return launch(conv16_pers_kernel<TZ, TY, R, VS, WPC>, P::NT, P::LDS_BYTES, grid, a, st, ntiles); \
     }
-                static const int pv = getenv("PCC_P16") ? atoi(getenv("PCC_P16")) : 0;
-                if (pv == 1) PCC_P16(2, 8, 2, 20, 1)     // one 8-wave workgroup per CU (same speed, fewer halo re-reads)
+                if (numerics & PCC_NUM_P16) PCC_P16(2, 8, 2, 20, 1)     // one 8-wave workgroup per CU (same speed, fewer halo re-reads)
                 PCC_P16(2, 4, 2, 20, 2)
 #undef PCC_P16
             }
@@ -1623,7 +1622,7 @@ int launch_fwd(int tx, ConvArgs a, hipStream_t st, int num_cu) {
 }
 
 template <int CIN, int COUT, int KS>
-int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
+int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu, uint32_t numerics) {
 #define PCC_TR2(TX, TZ, TY, TXT, R) PCC_TR2C(TX, TZ, TY, TXT, R, (COUT / 16))
 #define PCC_TR2C(TX, TZ, TY, TXT, R, CTW)                                                               \
     {                                                                                                   \
@@ -1654,7 +1653,7 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
         if (plain) PCC_TR2G_EPI(TX, TZ, TY, TXT, R, CTW, false, TR2G_EPI_F32)                           \
         PCC_TR2G_EPI(TX, TZ, TY, TXT, R, CTW, false, TR2G_EPI_ANY)                                      \
     }
-    static const bool tr2_old = getenv("PCC_TR2_OLD") != nullptr;
+    const bool tr2_old = (numerics & PCC_NUM_TR2_OLD) != 0;
     if (tx == 16) {
         if constexpr (KS == 3) { if (!tr2_old) { if constexpr (CIN >= 64) { PCC_TR2G(16, 2, 4, 16, 2, 2) } else { PCC_TR2G(16, 2, 8, 16, 4, 1) } } }
         if constexpr (CIN >= 64) PCC_TR2(16, 2, 4, 16, 2)
@@ -1684,10 +1683,10 @@ int launch_tr2(int tx, ConvArgs a, hipStream_t st, int num_cu) {
 #define PCC_TR2_P6(X) X(32, 16, 3) X(32, 32, 3)
 #define PCC_FWD_ALL(X) PCC_FWD_P1(X) PCC_FWD_P2(X) PCC_FWD_P3(X) PCC_FWD_P4(X)
 #define PCC_TR2_ALL(X) PCC_TR2_P4(X) PCC_TR2_P5(X) PCC_TR2_P6(X)
-#define PCC_INST_FWD(CI, CO, K, S) template int launch_fwd<CI, CO, K, S>(int, ConvArgs, hipStream_t, int);
-#define PCC_INST_TR2(CI, CO, K) template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t, int);
-#define PCC_EXT_FWD(CI, CO, K, S) extern template int launch_fwd<CI, CO, K, S>(int, ConvArgs, hipStream_t, int);
-#define PCC_EXT_TR2(CI, CO, K) extern template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t, int);
+#define PCC_INST_FWD(CI, CO, K, S) template int launch_fwd<CI, CO, K, S>(int, ConvArgs, hipStream_t, int, uint32_t);
+#define PCC_INST_TR2(CI, CO, K) template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t, int, uint32_t);
+#define PCC_EXT_FWD(CI, CO, K, S) extern template int launch_fwd<CI, CO, K, S>(int, ConvArgs, hipStream_t, int, uint32_t);
+#define PCC_EXT_TR2(CI, CO, K) extern template int launch_tr2<CI, CO, K>(int, ConvArgs, hipStream_t, int, uint32_t);
 #if PCC_PART == 0
 PCC_FWD_ALL(PCC_EXT_FWD)
 PCC_TR2_ALL(PCC_EXT_TR2)
@@ -1869,8 +1868,8 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
     a.ntz = a.nty = a.ntx = 0;
     const int ci = d->Cin, co = d->Cout, k = d->k, s = d->stride;
 
-#define PCC_CASE_FWD(CI, CO, K, S) if (ci == CI && co == CO && k == K && fs == S) return launch_fwd<CI, CO, K, S>(p.tx, a, st, ctx->num_cu);
-#define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st, ctx->num_cu);
+#define PCC_CASE_FWD(CI, CO, K, S) if (ci == CI && co == CO && k == K && fs == S) return launch_fwd<CI, CO, K, S>(p.tx, a, st, ctx->num_cu, ctx->numerics);
+#define PCC_CASE_TR2(CI, CO, K) if (ci == CI && co == CO && k == K) return launch_tr2<CI, CO, K>(p.tx, a, st, ctx->num_cu, ctx->numerics);
     PCC_REQUIRE(!(d->flags & PCC_CONV_OUT16) || p.kind == K_FWD || p.kind == K_TR2 || p.kind == K_CIN1,
                 "pcc_conv3d: PCC_CONV_OUT16 needs a layer with Cout a multiple of 16");
     if ((d->flags & (PCC_CONV_IN16 | PCC_CONV_RES16)) && p.kind != K_COUT1M) {
@@ -1891,17 +1890,15 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
                 PCC_REQUIRE(ci >= 32 && pcc_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)), "pcc_conv3d: PCC_IMPL_SPLIT covers fp32 k3 stride-1 layers with Cin = Cout in {32, 64}, W % 16 == 0");
                 return pcc_conv_split(ctx, d, in, w_split, bias, residual, out, st);
             }
-            if (d->impl == PCC_IMPL_AUTO && ci >= 32 && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && getenv("PCC_NO_SPLIT") == nullptr &&
-                getenv("PCC_NO_SPLIT_DIRECT") == nullptr && pcc_split_covers(d) && pcc_split_preferred(ctx, d))
+            if (d->impl == PCC_IMPL_AUTO && ci >= 32 && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_DIRECT) &&
+                pcc_split_covers(d) && pcc_split_preferred(ctx, d))
                 return pcc_conv_split(ctx, d, in, w_split, bias, residual, out, st);
-            static const bool no_wino = getenv("PCC_NO_WINOGRAD") != nullptr;
-            static const bool no_wino32 = getenv("PCC_NO_WINOGRAD32") != nullptr;
-            static const bool wino64 = getenv("PCC_NO_WINOGRAD64") == nullptr;
+            const bool no_wino = ctx->num(PCC_NUM_NO_WINOGRAD), no_wino32 = ctx->num(PCC_NUM_NO_WINOGRAD32), wino64 = !ctx->num(PCC_NUM_NO_WINOGRAD64);
             const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !(d->flags & PCC_CONV_F16) && !no_wino && !(ci == 32 && (no_wino32 || d->D < 16)) && !(ci == 64 && !wino64));
             if (want && pcc_wino_eligible(d)) {
                 const float* u32 = w_packed + (size_t)27 * ci * co;
                 // split-bf16 operands on the bf16 MFMA pipe (fp32-equivalent, conv_wino_bf16.hip); PCC_NO_SPLIT=1: exact-fp32 MFMA (A/B)
-                const bool split = getenv("PCC_NO_SPLIT") == nullptr && pcc_wino_bf16_covers(d);     // (read per call: tests flip it)
+                const bool split = !ctx->num(PCC_NUM_NO_SPLIT) && pcc_wino_bf16_covers(d);
                 if (split) return pcc_conv_wino_bf16(ctx, d, in, u32 + (size_t)(ci / 16) * (co / 16) * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(ci) / 4, bias, residual, out, st);
                 return pcc_conv_wino(ctx, d, in, u32, bias, residual, out, st);
             }
@@ -1915,14 +1912,14 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
     } else if (p.kind == K_TR2) {
         // 64 -> 32 / 64 -> 64: split-bf16 operands on the bf16 MFMA pipe (conv_tr2_split_kernel); shape-only rule, PCC_NO_SPLIT=1 /
         // PCC_NO_SPLIT_TR2=1: the exact-fp32 kernels below (A/B)
-        if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && getenv("PCC_NO_SPLIT") == nullptr &&
-            getenv("PCC_NO_SPLIT_TR2") == nullptr)
+        if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) &&
+            !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
             return pcc_conv_tr2_split(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, st);
         // z-marching kernel (conv_tr2m.hip) for the 32 -> 16 / 64 -> 32 layers on grids of 16-multiples.  PCC_NO_TR2M=1 keeps the
         // tiled conv_tr2g_kernel, PCC_TR2M=1 takes the marching kernel wherever it is eligible (A/B runs, tests)
-        if (getenv("PCC_NO_TR2M") == nullptr && (getenv("PCC_TR2M") != nullptr ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {
+        if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {
             // 32 -> 16: split-bf16 operands on the bf16 MFMA pipe (conv_tr2m_bf16.hip); PCC_NO_SPLIT=1 / PCC_NO_SPLIT_TR2=1: exact fp32 (A/B)
-            if (pcc_tr2m_bf16_covers(d) && getenv("PCC_NO_SPLIT") == nullptr && getenv("PCC_NO_SPLIT_TR2") == nullptr)
+            if (pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
                 return pcc_conv_tr2m_bf16(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, st);
             return pcc_conv_tr2m(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
         }
@@ -1940,7 +1937,7 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
     } else if (p.kind == K_COUT1M) {
         // 32 x 32 columns (one 16-wave workgroup per CU) when H, W allow it and the grid, z-split into slabs of >= 16 planes, still
         // gives every CU a workgroup; else 16 x 16 columns, whole z range.  PCC_COUT1_T16=1 forces the latter (A/B runs).
-        static const bool t16 = getenv("PCC_COUT1_T16") != nullptr;
+        const bool t16 = ctx->num(PCC_NUM_COUT1_T16);
         typedef void (*kern_t)(ConvArgs);
         const bool in16 = (d->flags & PCC_CONV_IN16) != 0;
         // the occupancy bits ride along when the caller asked for them and whole T-voxel rows map to whole mask pieces

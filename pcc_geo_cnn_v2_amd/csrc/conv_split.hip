@@ -795,7 +795,7 @@ int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const 
     a.flags = d->flags; a.ocs = d->out_cstride ? d->out_cstride : d->Cout; a.oco = d->out_coffset;
     // Which formulation: measured at batch 32 (tools/bench_one.py) -- 64 -> 64 @16^3: 128 us (16x16x32, tile 2 x 4 x 16) / 134 - 148 (32x32x16);
     // 32 -> 32 @16^3: 41 / 38.5 us; 32 -> 32 @32^3: 332 / 373 us.  A function of the layer shape only.  PCC_SPLIT_MFMA=16 | 32 overrides (A/B).
-    static const int force = getenv("PCC_SPLIT_MFMA") ? atoi(getenv("PCC_SPLIT_MFMA")) : 0;
+    const int force = ctx->num(PCC_NUM_SPLIT_MFMA16) ? 16 : ctx->num(PCC_NUM_SPLIT_MFMA32) ? 32 : 0;
     const bool use32 = force ? force == 32 : d->Cin == 32;
     if (d->W == 8) {
         // 64 -> 64 on the 8^3 grids (analysis block 3, first / last hyper layers): one z plane x 8 lines x 8 voxels per workgroup =
@@ -827,7 +827,7 @@ int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const 
     }
     // tile 2 x 4 x 16 (69 KB of LDS, two workgroups per CU: the second wave of a SIMD covers the first one's LDS / L2 waits) or
     // 2 x 8 x 16 (115 KB, one workgroup per CU, fewer halo voxels); PCC_SPLIT_TILE=8 selects the large one (A/B)
-    static const bool big = getenv("PCC_SPLIT_TILE") != nullptr && atoi(getenv("PCC_SPLIT_TILE")) == 8;
+    const bool big = ctx->num(PCC_NUM_SPLIT_TILE8);
 #define PCC_SPLIT_LAUNCH(CH, TZ, TY, R)                                                                            \
     {                                                                                                              \
         using C = SplitCfg<CH, TZ, TY, R, CH / 32>;                                                                \

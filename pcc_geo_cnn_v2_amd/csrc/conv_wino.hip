@@ -677,7 +677,7 @@ int pcc_conv_wino(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const f
     // multi-group layers take conv16_wino_cin_kernel unless they clip or PCC_WINO_PER_GROUP asks for one launch per cin group
     // (A/B runs; a test compares the two within the tolerance).  Measured (round 3, batch 32): 32 -> 32 @32^3 276 -> 251 us,
     // 64 -> 64 @16^3 172 -> 159 us.
-    const bool per_group = getenv("PCC_WINO_PER_GROUP") != nullptr;       // (read per call: a test flips it)
+    const bool per_group = ctx->num(PCC_NUM_WINO_PER_GROUP);
     // G = 2, 4: the cin groups inside the march, accumulators live across them (conv16_wino_cin_kernel), one launch
     if ((G == 2 || G == 4) && !(d->flags & PCC_CONV_CLIP01) && !per_group) {
         static const kern_t ck[4] = {conv16_wino_cin_kernel<false, 2>, conv16_wino_cin_kernel<true, 2>,

@@ -42,7 +42,38 @@ PCC_API int pcc_ctx_create(int device, pcc_ctx** out) {
         return PCC_ERR_NOGPU;
     }
     c->num_cu = c->prop.multiProcessorCount;
+    c->numerics = pcc_numerics_from_env();
     *out = c;
+    return PCC_OK;
+}
+
+// the ONE place the numerics-affecting environment switches are read (include/pcc_geo.h, PCC_NUM_*)
+uint32_t pcc_numerics_from_env() {
+    static const struct { const char* name; uint32_t bit; } flags[] = {
+        {"PCC_NO_SPLIT", PCC_NUM_NO_SPLIT}, {"PCC_NO_SPLIT_DIRECT", PCC_NUM_NO_SPLIT_DIRECT}, {"PCC_NO_SPLIT_TR2", PCC_NUM_NO_SPLIT_TR2},
+        {"PCC_NO_WINOGRAD", PCC_NUM_NO_WINOGRAD}, {"PCC_NO_WINOGRAD32", PCC_NUM_NO_WINOGRAD32}, {"PCC_NO_WINOGRAD64", PCC_NUM_NO_WINOGRAD64},
+        {"PCC_WINO_PER_GROUP", PCC_NUM_WINO_PER_GROUP}, {"PCC_NO_TR2M", PCC_NUM_NO_TR2M}, {"PCC_TR2M", PCC_NUM_TR2M},
+        {"PCC_TR2_OLD", PCC_NUM_TR2_OLD}, {"PCC_NO_SPLIT32M", PCC_NUM_NO_SPLIT32M}, {"PCC_COUT1_T16", PCC_NUM_COUT1_T16}};
+    uint32_t m = 0;
+    for (const auto& f : flags)
+        if (getenv(f.name) != nullptr) m |= f.bit;
+    if (const char* v = getenv("PCC_SPLIT_MFMA")) m |= atoi(v) == 16 ? PCC_NUM_SPLIT_MFMA16 : atoi(v) == 32 ? PCC_NUM_SPLIT_MFMA32 : 0u;
+    if (const char* v = getenv("PCC_SPLIT_TILE")) m |= atoi(v) == 8 ? PCC_NUM_SPLIT_TILE8 : 0u;
+    if (const char* v = getenv("PCC_P16")) m |= atoi(v) ? PCC_NUM_P16 : 0u;
+    return m;
+}
+
+PCC_API int pcc_ctx_get_numerics(pcc_ctx* ctx, uint32_t* family, uint32_t* switches) {
+    PCC_REQUIRE(ctx != nullptr, "pcc_ctx_get_numerics: ctx is NULL");
+    if (family) *family = PCC_KERNEL_FAMILY;
+    if (switches) *switches = ctx->numerics;
+    return PCC_OK;
+}
+
+PCC_API int pcc_ctx_set_numerics(pcc_ctx* ctx, uint32_t switches) {
+    PCC_REQUIRE(ctx != nullptr, "pcc_ctx_set_numerics: ctx is NULL");
+    PCC_REQUIRE((switches & ~0xffffu) == 0, "pcc_ctx_set_numerics: unknown bits 0x%x", switches & ~0xffffu);
+    ctx->numerics = switches;
     return PCC_OK;
 }
 

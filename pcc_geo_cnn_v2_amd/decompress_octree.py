@@ -30,7 +30,7 @@ def decompress(args):
     import torch
     from . import ops, sharding
     from .model_configs import ModelConfigType
-    from .model_syntax import load_compressed_file
+    from .model_syntax import check_numerics_tag, load_compressed_file, read_gzip_tag
     from .utils import pc_io
     from .utils.octree_coding import departition_octree
 
@@ -58,6 +58,7 @@ def decompress(args):
     model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size, precision=args.precision)
     compressed_data = []
     for file in args.input_files:
+        check_numerics_tag(read_gzip_tag(file), sess.numerics_tag(args.precision), ignore=args.ignore_numerics_tag)
         with gzip.open(file, 'rb') as f:
             compressed_data.append(load_compressed_file(f))
     model.decompress()
@@ -105,6 +106,8 @@ def build_parser():
     parser.add_argument('--data_format', default='channels_first', help='Data format used: channels_first or channels_last')
     parser.add_argument('--debug', default=False, action='store_true', help='Use debug data to check results.')
     parser.add_argument('--batch_size', type=int, default=32, help='Blocks resident on the GPU per pass (new).')
+    parser.add_argument('--ignore_numerics_tag', default=False, action='store_true',
+                        help='Decode although the stream was written under other codec numerics (kernel family / PCC_* switches / precision) (new).')
     parser.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
                         help='fp16: fp16 matrix instructions with fp32 accumulation on the conv layers (new; must match between '
                              'compress and decompress).')

@@ -90,3 +90,58 @@ def load_compressed_file(f):
     rest = bytes(cur.raw[cur.pos:])
     assert not rest, f'File not read completely file_end {rest[:64]}'
     return resolution, level, binstr, blocks
+
+
+# ---- the gzip wrapper of the CLIs (src/compress_octree.py:112, src/decompress_octree.py:61) with a codec-numerics tag ----------------
+# The container above is the reference's, byte for byte, and stays that way.  What it cannot say is which kernel family computed
+# sigma-hat on the encoder (include/pcc_geo.h, "codec numerics"): a decoder on another family flips scale indexes and the range decoder
+# desynchronises silently.  The tag rides in the gzip member header's FCOMMENT field (RFC 1952): `gzip.open` -- the reference's reader --
+# skips it, so a tagged file is still a valid input for the reference, and a file written by the reference simply has no tag.
+def write_tagged_gzip(path, payload, tag):
+    import zlib
+    comment = tag.encode('latin-1')
+    assert b'\0' not in comment
+    deflate = zlib.compressobj(9, zlib.DEFLATED, -15)
+    body = deflate.compress(payload) + deflate.flush()
+    with open(path, 'wb') as fh:
+        fh.write(b'\x1f\x8b\x08\x10' + struct.pack('<IBB', 0, 2, 255) + comment + b'\0')      # FLG = FCOMMENT, MTIME 0, XFL 2, OS unknown
+        fh.write(body)
+        fh.write(struct.pack('<II', zlib.crc32(payload) & 0xffffffff, len(payload) & 0xffffffff))
+
+
+def read_gzip_tag(path):
+    """The FCOMMENT of the first gzip member, or None (no comment / not a gzip file)."""
+    with open(path, 'rb') as fh:
+        head = fh.read(10)
+        if len(head) < 10 or head[:3] != b'\x1f\x8b\x08':
+            return None
+        flg = head[3]
+        if flg & 0x04:                                  # FEXTRA
+            n, = struct.unpack('<H', fh.read(2))
+            fh.read(n)
+
+        def cstring():
+            out = bytearray()
+            while True:
+                c = fh.read(1)
+                if not c or c == b'\0':
+                    return bytes(out)
+                out += c
+        if flg & 0x08:                                  # FNAME
+            cstring()
+        return cstring().decode('latin-1') if flg & 0x10 else None
+
+
+def check_numerics_tag(tag, expected, ignore=False):
+    """Decoder side.  No tag: a stream of the reference or of a build before the tag existed -- nothing to compare, logged.  Another
+    tag: refuse (or warn with ignore=True) -- the decoded cloud could be silent garbage."""
+    if tag is None or not tag.startswith('pcc_geo_cnn_v2_amd/'):
+        logger.warning('the stream carries no codec-numerics tag: it was written by another build; decoding with %s', expected)
+        return
+    if tag != expected:
+        msg = (f'the stream was encoded with codec numerics {tag}, this decoder computes {expected}: sigma-hat would differ in its last '
+               'bits, scale indexes flip and the range decoder desynchronises (set the same PCC_* switches / --precision, or pass '
+               '--ignore_numerics_tag to try anyway)')
+        if not ignore:
+            raise RuntimeError(msg)
+        logger.warning(msg)

@@ -3,6 +3,7 @@
 PyTorch-ROCm is plumbing only: it owns device memory (tensors) and streams; every operator below is
 a hand-written HIP kernel (or the host range coder) inside libpcc_geo_hip.so.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -27,6 +28,7 @@ class Context:
         L.check(L.lib().pcc_ctx_create(device, C.byref(h)), 'pcc_ctx_create')
         self.handle = h
         self.num_cu = L.lib().pcc_ctx_num_cu(h)
+        self.numerics_at_creation = self.numerics()[1]       # the PCC_* environment switches as pcc_ctx_create read them
 
     @property
     def stream(self):
@@ -41,6 +43,37 @@ class Context:
         return ws
 
     conv_flags = 0      # extra pcc_conv_desc.flags of every conv issued through this context (0 = the reference's fp32)
+
+    # ---- codec numerics (include/pcc_geo.h): which kernel family computes a layer is state of the context, read once from the PCC_*
+    #      environment switches at creation; encoder and decoder must agree on it (sigma-hat selects the entropy coder's rows)
+    def numerics(self):
+        """(kernel family of this build, PCC_NUM_* switches in effect)."""
+        fam, sw = C.c_uint32(), C.c_uint32()
+        L.check(L.lib().pcc_ctx_get_numerics(self.handle, C.byref(fam), C.byref(sw)), 'pcc_ctx_get_numerics')
+        return int(fam.value), int(sw.value)
+
+    def numerics_tag(self, precision='fp32'):
+        """What the CLIs record beside a stream (gzip header comment, .enc.metric.json) and the decoder compares."""
+        fam, sw = self.numerics()
+        return f'pcc_geo_cnn_v2_amd/k{fam}/sw{sw:04x}/{precision}'
+
+    def set_numerics(self, **switches):
+        """Replace named switches (L.PCC_NUM keys -> bool); returns the previous word.  Tests / A/B runs only: never between an
+        encode and the decode of its stream."""
+        _, old = self.numerics()
+        new = old
+        for k, v in switches.items():
+            new = (new | L.PCC_NUM[k]) if v else (new & ~L.PCC_NUM[k])
+        L.check(L.lib().pcc_ctx_set_numerics(self.handle, new), 'pcc_ctx_set_numerics')
+        return old
+
+    @contextlib.contextmanager
+    def numerics_override(self, **switches):
+        old = self.set_numerics(**switches)
+        try:
+            yield self
+        finally:
+            L.check(L.lib().pcc_ctx_set_numerics(self.handle, old), 'pcc_ctx_set_numerics')
 
     def view(self, conv_flags):
         """The same context (handle, device, stream, workspace) with other default conv flags -- how a model in the fp16 mode
@@ -724,11 +757,16 @@ def range_decode_batch(table, strings, n_list, index_list=None, index_mod=0, n_t
         if index_list is None:
             ip, ib, keep = None, 4, None
         else:
+            # one row per stream (2-D) or ONE row shared by all streams (1-D); a list of per-stream arrays belongs to the legacy path
+            # below (flattened here it would decode every stream with stream 0's rows)
+            assert not isinstance(index_list, (list, tuple)), 'range_decode_batch: a 2-D `out` takes a 2-D (or one shared 1-D) index array'
             i2 = _rows_2d(index_list, _ROW)
             if i2 is not None:
+                assert i2.shape == o2.shape, f'range_decode_batch: index rows {i2.shape} for symbols {o2.shape}'
                 keep, ib, ip = i2, i2.dtype.itemsize, _row_ptrs(i2)
             else:
                 keep = _np_host(index_list, _ROW)
+                assert keep.ndim == 1 and keep.size == n_sym, f'range_decode_batch: shared index of {keep.size} rows for {n_sym} symbols'
                 ib, ip = keep.dtype.itemsize, np.full(S, keep.ctypes.data, np.uint64)
         lens = np.fromiter((len(s_) for s_ in strings), np.uint64, S)
         blob = np.frombuffer(b''.join(strings) + b'\0', np.uint8)            # all strings in one buffer: pointers by offset

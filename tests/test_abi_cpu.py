@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f'symbols declared in pcc_geo.h but not exported: {missing}'
     assert set(L.EXPORTS) <= declared
-    assert L.lib().pcc_abi_version() == L.ABI_VERSION == 3
+    assert L.lib().pcc_abi_version() == L.ABI_VERSION == 4
 
 
 def test_network_layer_tables_match_the_oracle_restatement(oracle):

@@ -145,11 +145,8 @@ def test_winograd_at_the_real_launch_geometry_matches_oracle(ctx, oracle, N, ch,
     import os
     got32 = None
     if ch == 16:
-        os.environ['PCC_NO_SPLIT'] = '1'
-        try:
+        with ctx.numerics_override(no_split=True):
             got32 = ops.conv3d(ctx, x.to(ctx.device), layer, residual=r.to(ctx.device), impl=L.PCC_IMPL_WINOGRAD).cpu()
-        finally:
-            del os.environ['PCC_NO_SPLIT']
     worst32, rel = 0.0, 0.0
     for n0 in range(0, N, 4):                      # the oracle in batches of 4 blocks (bounded host memory)
         ref = T.conv3d_transpose(x[n0:n0 + 4], w, b, 1, True) + r[n0:n0 + 4]
@@ -188,11 +185,8 @@ def test_split_layers_at_the_bench_launch_geometry_match_oracle(ctx, oracle, nam
     got = ops.conv3d(ctx, xd, layer, residual=rd)
     one = ops.conv3d(ctx, xd[N - 1:].contiguous(), layer, residual=None if rd is None else rd[N - 1:].contiguous())
     assert torch.equal(got[N - 1:], one), 'the result depends on the batch / launch geometry'
-    os.environ['PCC_NO_SPLIT'] = '1'
-    try:
+    with ctx.numerics_override(no_split=True):
         exact = ops.conv3d(ctx, xd, layer, residual=rd)
-    finally:
-        del os.environ['PCC_NO_SPLIT']
     assert not torch.equal(got, exact), 'AUTO did not take a split kernel'
     got, exact = got.cpu(), exact.cpu()
     worst = worst32 = 0.0
@@ -222,9 +216,9 @@ def test_split_bf16_winograd_covers_the_fp32_exponent_range_and_is_deterministic
     assert torch.equal(a, ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_WINOGRAD))
     assert torch.equal(a[1:2], ops.conv3d(ctx, x[1:2].contiguous(), layer, impl=L.PCC_IMPL_WINOGRAD))          # other grid, other z split
     ref = oracle.conv3d(x.cpu().numpy(), w, b, 1, False)
-    monkeypatch.setenv('PCC_NO_SPLIT', '1')
+    ctx.set_numerics(no_split=True)
     f32 = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_WINOGRAD)
-    monkeypatch.delenv('PCC_NO_SPLIT')
+    ctx.set_numerics(no_split=False)
     bound = 8e-6 * (1 + np.abs(ref).max())
     assert np.abs(a.cpu().numpy() - ref).max() <= bound and np.abs(f32.cpu().numpy() - ref).max() <= bound
     assert not torch.equal(a, f32)                 # (two kernels, two summation orders: the env switch really switches)
@@ -272,13 +266,13 @@ def test_stride2_transposed_split_bf16_conv_matches_oracle(ctx, oracle, monkeypa
     layer = ops.ConvLayer(w, rng.standard_normal(cout).astype(np.float32) if bias else None, 2, True, relu)
     a = ops.conv3d(ctx, x, layer)
     assert torch.equal(a, ops.conv3d(ctx, x, layer)) and torch.equal(a[N - 1:], ops.conv3d(ctx, x[N - 1:].contiguous(), layer))
-    monkeypatch.setenv('PCC_NO_SPLIT_TR2', '1')
+    ctx.set_numerics(no_split_tr2=True)
     b = ops.conv3d(ctx, x, layer)
     assert got.shape == (N, 2 * D, 2 * H, 2 * W, cout)
     assert not torch.equal(a, b), 'AUTO did not select the split kernel'
     assert (a - b).abs().max().item() <= 2e-5 * (1 + b.abs().max().item())
     out = torch.zeros((N, 2 * D, 2 * H, 2 * W, cout + 16), device=ctx.device)      # concat offset / channel stride
-    monkeypatch.delenv('PCC_NO_SPLIT_TR2')
+    ctx.set_numerics(no_split_tr2=False)
     ops.conv3d(ctx, x, layer, out=out, out_coffset=8)
     assert torch.equal(out[..., 8:8 + cout], a) and not out[..., :8].any() and not out[..., 8 + cout:].any()
 
@@ -297,7 +291,7 @@ def test_marching_stride2_transposed_conv_matches_oracle(ctx, oracle, monkeypatc
     the accumulators of three output planes live -- against the C oracle (TF SAME crop 0 low / 1 high); bit-deterministic and
     independent of batch / z split; within the tolerance of the tiled conv_tr2g_kernel (same taps, another summation order)."""
     N, D, H, W, cin, cout, bias, relu = case
-    monkeypatch.setenv('PCC_TR2M', '1')                     # also where AUTO would prefer the tiled kernel (64 -> 32 on short slabs)
+    ctx.set_numerics(tr2m=True)                     # also where AUTO would prefer the tiled kernel (64 -> 32 on short slabs)
     got = _run(ctx, oracle, N, D, H, W, cin, cout, 3, 2, True, bias, relu, False, L.PCC_IMPL_MFMA, seed=41)
     rng = np.random.default_rng(41)
     x = torch.from_numpy(rng.standard_normal((N, D, H, W, cin)).astype(np.float32)).to(ctx.device)
@@ -306,8 +300,8 @@ def test_marching_stride2_transposed_conv_matches_oracle(ctx, oracle, monkeypatc
     a = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
     a2 = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
     one = ops.conv3d(ctx, x[N - 1:].contiguous(), layer, impl=L.PCC_IMPL_MFMA)       # other grid / z split
-    monkeypatch.delenv('PCC_TR2M')
-    monkeypatch.setenv('PCC_NO_TR2M', '1')
+    ctx.set_numerics(tr2m=False)
+    ctx.set_numerics(no_tr2m=True)
     b = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_MFMA)
     torch.cuda.synchronize()
     assert got.shape == (N, 2 * D, 2 * H, 2 * W, cout)
@@ -347,9 +341,9 @@ def test_last_layer_32x32_columns_match_reference_order_kernel(ctx, monkeypatch,
     x = torch.randn((N, D, HW, HW, 16), generator=torch.Generator().manual_seed(D)).to(ctx.device)
     a = ops.conv3d(ctx, x, layer)
     a2 = ops.conv3d(ctx, x, layer)
-    monkeypatch.setenv('PCC_COUT1_T16', '1')
+    ctx.set_numerics(cout1_t16=True)
     b = ops.conv3d(ctx, x, layer)
-    monkeypatch.delenv('PCC_COUT1_T16')
+    ctx.set_numerics(cout1_t16=False)
     torch.cuda.synchronize()
     # same bits as the 16 x 16 columns (per output: channels -> (ky, kx) -> kz, whatever the column / slab geometry): encoder
     # and decoder may chunk differently and still have to agree on x_hat
@@ -434,9 +428,9 @@ def test_winograd_cin_groups_inside_the_march(ctx, monkeypatch, C, N, D, H, W, t
     a = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_WINOGRAD)
     a2 = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_WINOGRAD)
     one = ops.conv3d(ctx, x[N - 1:].contiguous(), layer, residual=None if r is None else r[N - 1:].contiguous(), impl=L.PCC_IMPL_WINOGRAD)
-    monkeypatch.setenv('PCC_WINO_PER_GROUP', '1')
+    ctx.set_numerics(wino_per_group=True)
     b = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_WINOGRAD)
-    monkeypatch.delenv('PCC_WINO_PER_GROUP')
+    ctx.set_numerics(wino_per_group=False)
     d = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_MFMA)
     torch.cuda.synchronize()
     assert torch.equal(a, a2) and torch.equal(a[N - 1:], one)          # deterministic; independent of batch / z split

@@ -2,15 +2,13 @@
 # Runs on the GPU box (via gpurun): rocprofv3 evidence for profiles/.  Usage: tools/profile_round.sh <tag>
 # No trace domain other than --kernel-trace is ever combined with --pmc (gpurun refuses that), counters in separate passes.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-# (1) per-kernel time of the benchmark command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 180 python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_profiled.log 2>&1
-# (2) counters of the three kernels VERDICT names, separate passes each: <key> <bench_one shape>
+# (2) counters of the kernels VERDICT names, separate passes each: <key> <bench_one shape>
 pmc() {
   KEY=$1; shift
   CMD="python $R/tools/bench_one.py $*"
@@ -22,6 +20,12 @@ pmc() {
   PCC_BENCH_IMPL=0 timeout 120 $CMD 2>&1 | grep -v amdgpu.ids > $OUT/$KEY/time.log
 }
 pmc wino16 32 64 16 16 3 1 1 res
+# profiles/dominant_kernel_traffic.json from these passes BEFORE any bench run below, so that their traffic_profiled object is not stale
+python $R/tools/summarize_round.py $TAG --traffic-only && cp $R/profiles/dominant_kernel_traffic.json $OUT/dominant_kernel_traffic.json
+# (1) per-kernel time of the benchmark command: 15 steps, all of them traced and counted (no set-up priming, no A/B, no secondary)
+TRACE_CMD="python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-ab"
+echo "PCC_BENCH_NO_PRIME=1 $TRACE_CMD" > $OUT/trace_cmd.txt; echo 15 > $OUT/trace_steps.txt
+PCC_BENCH_NO_PRIME=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 180 python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-ab > $OUT/bench_profiled.log 2>&1
 export PCC_NO_SPLIT=1; pmc wino16_fp32 32 64 16 16 3 1 1 res; unset PCC_NO_SPLIT
 pmc cin32 32 32 32 32 3 1 1 res
 pmc cin64 32 16 64 64 3 1 1 res
@@ -30,7 +34,7 @@ pmc tr2g 32 16 64 32 3 2 1
 pmc cout1 32 64 16 1 3 1 1
 pmc fwd64_8 32 8 64 64 3 1 0
 # (3) un-profiled bench line for comparison
-cd $R && python bench.py --steps 20 --warmup 3 > $OUT/bench.log 2>&1
+cd $R && python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1
 # keep what travels back small
 find $OUT -name "*agent_info.csv" -delete
 tail -1 $OUT/bench.log | cut -c1-300

@@ -1,14 +1,24 @@
-"""Turns gpurun_out/<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/."""
+"""Turns gpurun_out/<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/.
+
+    python tools/summarize_round.py <tag>                 everything
+    python tools/summarize_round.py <tag> --traffic-only  only profiles/dominant_kernel_traffic.json (run ON the GPU box by profile_round.sh right
+                                                          after the counter passes of the dominant kernel, so that the bench runs that follow embed
+                                                          a traffic_profiled object that is not stale)"""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import summarize_trace as ST
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+TRAFFIC_ONLY = '--traffic-only' in sys.argv
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(src, 'trace', '**', 't_kernel_stats.csv'), recursive=True)[0], os.path.join(dst, f'{tag}_bench_kernel_stats.csv'))
-summary = subprocess.check_output([sys.executable, os.path.join(root, 'tools', 'summarize_trace.py'),
-                                   glob.glob(os.path.join(src, 'trace', '**', 't_kernel_trace.csv'), recursive=True)[0], '6', '34'], text=True)
-bench_prof = [l for l in open(os.path.join(src, 'bench_profiled.log')) if l.startswith('{"metric"')]
-bench = [l for l in open(os.path.join(src, 'bench.log')) if l.startswith('{"metric"')]
+TRACE_STEPS = int(open(os.path.join(src, 'trace_steps.txt')).read()) if os.path.exists(os.path.join(src, 'trace_steps.txt')) else 6
+if not TRAFFIC_ONLY:
+    shutil.copy(glob.glob(os.path.join(src, 'trace', '**', 't_kernel_stats.csv'), recursive=True)[0], os.path.join(dst, f'{tag}_bench_kernel_stats.csv'))
+    trace_agg = ST.load(glob.glob(os.path.join(src, 'trace', '**', 't_kernel_trace.csv'), recursive=True)[0])
+    summary, trace_stats = ST.table(trace_agg, TRACE_STEPS, 34)
+    bench_prof = [l for l in open(os.path.join(src, 'bench_profiled.log')) if l.startswith('{"metric"')]
+    bench = [l for l in open(os.path.join(src, 'bench.log')) if l.startswith('{"metric"')]
 PEAK_TF, HBM_TBS = 157.3, 8.0
 B = 32
 # key -> (kernel name fragment, description, algorithmic flops per launch, executed-MFMA flops per launch (None = counter), algorithmic bytes, bound)
@@ -32,6 +42,10 @@ KERNELS = {
 }
 rows, traffic_json = [], None
 for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
+    if TRAFFIC_ONLY and key != 'wino16':
+        continue
+    if not os.path.exists(os.path.join(src, key, 'time.log')):
+        continue
     pmc, dur = {}, []
     for d in ('fetch', 'write', 'sq', 'lds'):
         for f in glob.glob(os.path.join(src, key, d, '**', '*counter_collection.csv'), recursive=True):
@@ -82,10 +96,34 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
         traffic_json = dict(out, kernel_source=ksrc, kernel_source_sha1=hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest(), method='rocprofv3 --pmc, one pass per counter group, on tools/bench_one.py 32 64 16 16 3 1 1 res; FETCH_SIZE doubled per '
                             'MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B fabric request); WRITE_SIZE as reported (uncalibrated)')
 json.dump(traffic_json, open(os.path.join(dst, 'dominant_kernel_traffic.json'), 'w'), indent=1)
+if TRAFFIC_ONLY:
+    sys.exit(0)
 json.dump(rows, open(os.path.join(dst, f'{tag}_kernel_counters.json'), 'w'), indent=1)
+# the dominant kernel inside the traced bench (its 64^3 launches = the (kernel, grid) row with the largest total among its rows)
+dom_rows = [(k, v) for k, v in trace_stats.items() if 'conv16_wino_bf16' in k[0] or 'conv16_wino2_bf16' in k[0]]
+dom_key, dom = max(dom_rows, key=lambda kv: kv[1]['total']) if dom_rows else (None, None)
+DOM_BYTES = 3.0 * B * 64 ** 3 * 16 * 4
+DOM_EXEC_BF16 = 6.0 * 2.0 * B * 64 ** 3 * 27 * 16 * 16 * (16.0 / 36.0) * ((64 + 1 - 4.0 / 3.0) / 64)      # bench.py wino_exec_factor(16, 64, 32) x six bf16 product terms
+trace_cmd = open(os.path.join(src, 'trace_cmd.txt')).read().strip() if os.path.exists(os.path.join(src, 'trace_cmd.txt')) else 'python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary'
 with open(os.path.join(dst, f'{tag}_bench_kernel_summary.md'), 'w') as f:
-    f.write(f'# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary`\n\n')
-    f.write('6 steps of 32 blocks (1 warm-up + 5 timed), c3p @64^3, per (kernel, grid size):\n\n' + summary + '\n')
+    f.write(f'# {tag}: `rocprofv3 --kernel-trace --stats -- {trace_cmd}`\n\n')
+    f.write(f'{TRACE_STEPS} steps of 32 blocks in the traced process (set-up priming + warm-up + timed, all counted), c3p @64^3, per (kernel, grid size).  '
+            'avg = what `--stats` prints (includes the first launch of every kernel, which pays the code-object load); median / trimmed mean = the steady state:\n\n' + summary + '\n\n')
+    if dom is not None:
+        med, trim = dom['median'] * 1e-9, dom['trimmed'] * 1e-9
+        f.write('## The roofline numbers of the bench line, recomputed from THIS trace\n\n')
+        f.write(f'Dominant kernel `{dom_key[0]}` (grid {dom_key[1]}): {dom["calls"]} launches = {dom["calls"] / TRACE_STEPS:.2f} per step, median {med*1e6:.1f} us, trimmed mean {trim*1e6:.1f} us, '
+                f'average {dom["avg"]/1e3:.1f} us, max {dom["max"]/1e3:.1f} us.\n\n')
+        f.write('| from | launch us | algorithmic bytes / launch | TB/s | `roofline.frac` (of 8 TB/s) | executed bf16 GFLOP / launch | TFLOP/s | frac of 2.5 PF (`roofline.mfma.frac_of_bf16_mfma_peak`) |\n|---|---|---|---|---|---|---|---|\n')
+        for name, t in (('trace median', med), ('trace trimmed mean', trim)):
+            f.write(f'| {name} | {t*1e6:.1f} | {DOM_BYTES/1e9:.4f} GB | {DOM_BYTES/t/1e12:.2f} | **{DOM_BYTES/t/8e12:.3f}** | {DOM_EXEC_BF16/1e9:.1f} | {DOM_EXEC_BF16/t/1e12:.0f} | {DOM_EXEC_BF16/t/2.5e15:.3f} |\n')
+        for name, lines in (('bench.py under the profiler (HIP events)', bench_prof), ('bench.py without the profiler (HIP events)', bench)):
+            if lines:
+                r = json.loads(lines[-1])['roofline']
+                t = r['avg_launch_ms'] * 1e-3
+                f.write(f'| {name} | {t*1e6:.1f} | {r["algorithmic_bytes_per_launch"]/1e9:.4f} GB | {r["algorithmic_bytes_per_launch"]/t/1e12:.2f} | **{r["frac"]:.3f}** | '
+                        f'{r.get("mfma", {}).get("executed_bf16_flops_per_launch", float("nan"))/1e9:.1f} | {r.get("mfma", {}).get("executed_bf16_tflops", float("nan")):.0f} | {r.get("mfma", {}).get("frac_of_bf16_mfma_peak", float("nan")):.3f} |\n')
+        f.write('\n')
     f.write('bench.py JSON under the profiler:\n\n```\n' + ''.join(bench_prof) + '```\n\nbench.py JSON without the profiler (same box):\n\n```\n' + ''.join(bench) + '```\n\n')
     f.write('## Counters of the kernels the verdicts name (separate `--pmc` passes on `tools/bench_one.py`, batch 32)\n\n')
     f.write('| kernel | launch us (median, un-profiled) | executed MFMA GFLOP | executed frac of the peak of its pipe (157.3 TF fp32 or 2500 TF bf16) | MFMA busy / SIMD cycles | MFMA busy / wave cycles | clock GHz (counter pass) | '
