@@ -99,3 +99,49 @@ def test_cli_sharded_over_two_ranks_writes_the_single_process_file(tmp_path):
     for i in (1, 2):
         assert np.array_equal(pc_io.load_pc(a[i]), pc_io.load_pc(b[i]))
     assert np.array_equal(pc_io.load_pc(b[1]), pc_io.load_pc(b[2]))   # decoder == encoder-side reconstruction
+
+
+def test_cli_stream_carries_its_codec_numerics_and_the_decoder_refuses_another_family(tmp_path):
+    """sigma-hat selects the entropy coder's rows, so a stream written under one kernel family (exact-fp32 MFMA vs split-bf16,
+    fp32 vs fp16 mode) must not be decoded under another.  compress_octree records the context's numerics tag in the gzip member header
+    (the container bytes stay the reference's, /root/reference/src/model_syntax.py:20-35); decompress_octree refuses a mismatch, decodes
+    with --ignore_numerics_tag, and decodes an untagged (reference-written) file with a warning.  The PCC_* switches reach the context
+    through the environment at creation, once."""
+    res, level = 64, 1
+    src, ck = str(tmp_path / 'in.ply'), str(tmp_path / 'ckpt')
+    pc_io.write_df(src, pc_io.pa_to_df(_cloud(res, 3)))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    run = lambda e, *a: subprocess.run([sys.executable, '-m'] + list(a), cwd=ROOT, env=e, capture_output=True, text=True)
+    assert run(env, 'pcc_geo_cnn_v2_amd.init_checkpoint', '--model_config', 'c3p', '--checkpoint_dir', ck).returncode == 0
+    out, dec = str(tmp_path / 'a.ply.bin'), str(tmp_path / 'dec.ply')
+    enc = ['pcc_geo_cnn_v2_amd.compress_octree', '--input_files', src, '--output_files', out, '--checkpoint_dir', ck, '--model_config', 'c3p',
+           '--resolution', str(res), '--octree_level', str(level), '--opt_metrics', 'd1_mse', '--fixed_threshold']
+    p = run(env, *enc)
+    assert p.returncode == 0, p.stderr[-2000:]
+    tag = model_syntax.read_gzip_tag(out)
+    assert tag is not None and tag.startswith('pcc_geo_cnn_v2_amd/k') and tag.endswith('/sw0000/fp32'), tag
+    decode = ['pcc_geo_cnn_v2_amd.decompress_octree', '--input_files', out, '--output_files', dec, '--checkpoint_dir', ck, '--model_config', 'c3p']
+    assert run(env, *decode).returncode == 0
+    ref_pts = pc_io.load_pc(dec)
+    # another kernel family on the decoder (PCC_NO_SPLIT=1 -> numerics switch 0x1): refused, loudly
+    other = dict(env, PCC_NO_SPLIT='1')
+    p = run(other, *decode)
+    assert p.returncode != 0 and 'codec numerics' in p.stderr and 'sw0001' in p.stderr, p.stderr[-2000:]
+    p = run(env, *(decode + ['--precision', 'fp16']))
+    assert p.returncode != 0 and 'codec numerics' in p.stderr
+    assert run(other, *(decode + ['--ignore_numerics_tag'])).returncode in (0, 1)      # tries; may legitimately fail on a desynchronised stream
+    # the same switch on BOTH sides: a consistent pair again, tagged as such
+    out2 = str(tmp_path / 'b.ply.bin')
+    p = run(other, *(enc[:4] + [out2] + enc[5:]))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert model_syntax.read_gzip_tag(out2).endswith('/sw0001/fp32')
+    assert run(other, 'pcc_geo_cnn_v2_amd.decompress_octree', '--input_files', out2, '--output_files', dec, '--checkpoint_dir', ck, '--model_config', 'c3p').returncode == 0
+    # a file as the reference writes it (plain gzip.open, no tag): decoded, with a warning
+    with gzip.open(out, 'rb') as f:
+        payload = f.read()
+    plain = str(tmp_path / 'plain.ply.bin')
+    with gzip.open(plain, 'wb') as f:
+        f.write(payload)
+    p = run(env, 'pcc_geo_cnn_v2_amd.decompress_octree', '--input_files', plain, '--output_files', dec, '--checkpoint_dir', ck, '--model_config', 'c3p')
+    assert p.returncode == 0 and 'no codec-numerics tag' in p.stderr, p.stderr[-2000:]
+    assert np.array_equal(pc_io.load_pc(dec), ref_pts)

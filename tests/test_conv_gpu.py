@@ -543,3 +543,28 @@ def test_direct_split_bf16_conv_is_deterministic_geometry_invariant_and_as_accur
     base = ops.conv3d(ctx, x, nobias, impl=L.PCC_IMPL_SPLIT)
     for e in (-50, 30):
         assert torch.equal(ops.conv3d(ctx, x * (2.0 ** e), nobias, impl=L.PCC_IMPL_SPLIT), base * (2.0 ** e)), e
+
+
+def test_kernel_family_switches_are_context_state_not_per_call_environment(ctx, monkeypatch):
+    """the switches that select the kernel family of a layer were read inconsistently (some per call, some cached in statics).
+    They are one word on the context now: read from the PCC_* environment once at pcc_ctx_create, changed only through
+    pcc_ctx_set_numerics; flipping the environment afterwards changes nothing; unknown bits are rejected."""
+    fam, sw = ctx.numerics()
+    assert fam >= 5 and sw == ctx.numerics_at_creation
+    assert ctx.numerics_tag() == f'pcc_geo_cnn_v2_amd/k{fam}/sw{sw:04x}/fp32'
+    rng = np.random.default_rng(7)
+    w = (rng.standard_normal((3, 3, 3, 16, 16)) / np.sqrt(27 * 16)).astype(np.float32)
+    layer = ops.ConvLayer(w, None, 1, False, False)
+    x = torch.from_numpy(rng.standard_normal((1, 16, 16, 16, 16)).astype(np.float32)).to(ctx.device)
+    a = ops.conv3d(ctx, x, layer)
+    monkeypatch.setenv('PCC_NO_SPLIT', '1')                  # too late for this context: no effect
+    assert torch.equal(a, ops.conv3d(ctx, x, layer)) and ctx.numerics()[1] == sw
+    with ctx.numerics_override(no_split=True):
+        assert ctx.numerics()[1] == sw | L.PCC_NUM['no_split'] and ctx.numerics_tag().endswith(f'/sw{sw | 1:04x}/fp32')
+        b = ops.conv3d(ctx, x, layer)
+    assert ctx.numerics()[1] == sw and not torch.equal(a, b) and (a - b).abs().max().item() < 1e-5
+    fresh = ops.Context(0)                                    # a context created NOW sees the variable
+    assert fresh.numerics()[1] & L.PCC_NUM['no_split'] and torch.equal(ops.conv3d(fresh, x, layer), b)
+    fresh.close()
+    import ctypes as C
+    assert L.lib().pcc_ctx_set_numerics(ctx.handle, C.c_uint32(1 << 20)) == L.PCC_ERR_ARG

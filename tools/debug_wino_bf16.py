@@ -12,9 +12,8 @@ def run(name, w, x, bias=None):
     xt = torch.from_numpy(x.astype(np.float32)).to(ctx.device)
     ref = ops.conv3d(ctx, xt, layer, impl=L.PCC_IMPL_MFMA).cpu().numpy()
     got = ops.conv3d(ctx, xt, layer, impl=L.PCC_IMPL_WINOGRAD).cpu().numpy()
-    os.environ['PCC_NO_SPLIT'] = '1'
-    f32 = ops.conv3d(ctx, xt, layer, impl=L.PCC_IMPL_WINOGRAD).cpu().numpy()
-    del os.environ['PCC_NO_SPLIT']
+    with ctx.numerics_override(no_split=True):
+        f32 = ops.conv3d(ctx, xt, layer, impl=L.PCC_IMPL_WINOGRAD).cpu().numpy()
     e = np.abs(got - ref); e32 = np.abs(f32 - ref)
     print(f'{name}: max|ref| {np.abs(ref).max():.4g}  err split {e.max():.3e}  err fp32-wino {e32.max():.3e}  nan {np.isnan(got).sum()}')
     if e.max() > 1e-3 * (1 + np.abs(ref).max()):

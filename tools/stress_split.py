@@ -46,9 +46,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     a = ops.conv3d(ctx, x, layer, residual=r, impl=impl_a, flags=fl)
     a2 = ops.conv3d(ctx, x, layer, residual=r, impl=impl_a, flags=fl)
     if impl_b is None:
-        os.environ['PCC_NO_SPLIT_TR2'] = '1'
-        d = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_AUTO, flags=fl)
-        del os.environ['PCC_NO_SPLIT_TR2']
+        with ctx.numerics_override(no_split_tr2=True):
+            d = ops.conv3d(ctx, x, layer, residual=r, impl=L.PCC_IMPL_AUTO, flags=fl)
     else:
         d = ops.conv3d(ctx, x, layer, residual=r, impl=impl_b, flags=fl)
     err = (a - d).abs().max().item(); ref = d.abs().max().item()
