@@ -138,6 +138,9 @@ def compress(args):
     from .utils.octree_coding import partition_octree
 
     clouds, with_normals = _plan(args)
+    if getattr(args, 'd2_search', None):
+        from . import model_opt
+        model_opt.D2_SEARCH = args.d2_search
     rank, world, local = _join_process_group()
     if args.debug and world > 1:
         raise AssertionError('--debug dumps every intermediate of every block: run it on one GPU')
@@ -200,6 +203,10 @@ def build_parser():
     parser.add_argument('--data_format', default='channels_first', help='Data format used: channels_first or channels_last')
     parser.add_argument('--debug', default=False, action='store_true', help='Output debug data for point cloud.')
     parser.add_argument('--batch_size', type=int, default=32, help='Blocks resident on the GPU per pass (new).')
+    parser.add_argument('--d2_search', default=None, choices=['gpu', 'kdtree'],
+                        help='Where the d2_* statistics of the adaptive threshold search come from (new): gpu = nearest-index transforms, ties '
+                             'between equidistant neighbours go to the lowest (x, y, z); kdtree = scipy KD-trees on the host, the '
+                             "reference's own picks and decisions (8-18x slower per cloud).  Default: kdtree (PCC_D2_GPU=1 = gpu).")
     parser.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
                         help='fp16: fp16 matrix instructions with fp32 accumulation on the conv layers (new; must match between '
                              'compress and decompress).')

@@ -242,10 +242,26 @@ def gpu_search_supported(opt_metrics, dhw):
     return max(dhw) <= 128
 
 
+D2_SEARCH = None      # 'kdtree' | 'gpu': set by the CLIs' --d2_search; None = the environment (PCC_D2_GPU=1 -> 'gpu') or 'kdtree'
+_d2_logged = False
+
+
 def d2_on_gpu():
-    """d2_* statistics come from the GPU unless PCC_D2_HOST=1 asks for the round-3 path (scipy KD-trees in a worker pool: the
-    reference's own tie pick, 30x slower; A/B runs and the tie analysis of tests/test_threshold_search_gpu.py)."""
-    return os.environ.get('PCC_D2_HOST') is None
+    """Where the d2_* statistics of the adaptive search come from.  DEFAULT (round 5): scipy KD-trees in the host worker pool
+    -- the reference's own neighbour picks (pc_metric.py:114: among equidistant nearest neighbours it takes whatever the tree traversal
+    returns), hence the reference's decisions (pinned by tests/golden/model_opt_d2.npz).  OPT-IN (--d2_search gpu / PCC_D2_GPU=1): the
+    nearest-index transforms of csrc/threshold_search.hip, 8-18x faster per cloud, ties to the lowest (x, y, z).  The two agree exactly
+    where no tie occurs (tests/golden/model_opt_d2_tiefree.npz); on voxelised surfaces ties are the rule: measured (tools/d2_tie_table.py,
+    DESIGN.md 3.8) the d2_mse decision differs on 82-89 % of the blocks of a 1024^3 cloud and the D2 PSNR of the d2-optimised stream,
+    evaluated with the reference's metric, drops by 0.2-1.2 dB -- the search then minimises a function other than the one it is judged by.
+    d1_* metrics never depend on the pick and always come from the GPU."""
+    global _d2_logged
+    mode = D2_SEARCH or ('kdtree' if os.environ.get('PCC_D2_HOST') is not None else 'gpu' if os.environ.get('PCC_D2_GPU') is not None else 'kdtree')
+    if mode == 'gpu' and not _d2_logged:
+        _d2_logged = True
+        logger.warning('d2_* threshold search on the GPU (opt-in): equidistant nearest neighbours resolve to the lowest (x, y, z), not to '
+                       'scipy\'s KD-tree pick as in the reference; decisions differ on most blocks of a voxelised surface (DESIGN.md 3.8)')
+    return mode == 'gpu'
 
 
 def d1_tallies_gpu(ctx, blocks, x_hat, thresholds):
@@ -296,14 +312,17 @@ def d12_tallies_gpu(ctx, blocks, x_hat, thresholds):
 
 
 def mean_point_tally(block, with_normals):
-    """Tally of the rounded mean point (the guard of model_opt.py:59-68) without a KD-tree: its nearest original point by a plain
-    argmin (lowest index on a tie, the rule of the GPU path)."""
+    """Tally of the rounded mean point (the guard of model_opt.py:59-68) without a KD-tree: its nearest original point; among
+    equidistant ones the lowest (x, y, z) in lexicographic order -- the tie rule of the GPU path (csrc/threshold_search.hip), whatever
+    order the block's points are stored in (a plain argmin is that rule only for sorted blocks)."""
     blk = np.asarray(block)
     if not with_normals:
         return mean_point_d1_tally(blk)
     a = blk[:, :3]
     mean_point = np.round(np.mean(a, axis=0))[np.newaxis, :]
-    to_a = np.array([int(np.argmin(PM.squared_norms(a - mean_point)))], np.int64)
+    d = PM.squared_norms(a - mean_point)
+    near = np.flatnonzero(d == d.min())
+    to_a = np.array([int(near[np.lexsort((a[near, 2], a[near, 1], a[near, 0]))[0]])], np.int64)
     return PM.pair_tally(a, mean_point, np.zeros(len(a), np.int64), to_a, blk[:, blk.shape[1] - 3:])
 
 

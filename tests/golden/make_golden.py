@@ -159,9 +159,71 @@ def round3(model_opt, pc_metric, octree_coding):
     print('round-3 fixtures written')
 
 
+def round5(model_opt, pc_metric):
+    """Round-5 fixture: the reference's D2 threshold DECISIONS where they are defined without a tie rule.  Every block of
+    model_opt_d2.npz contains equidistant nearest neighbours at every level set (voxelised shells), so the d2_* picks of the reference
+    there are whatever scipy's KD-tree traversal returns.  Here: sparse blocks (a handful of scattered points with random normals
+    against a handful of decoded voxels of distinct values, so the level sets shrink one voxel at a time) searched until EVERY level set
+    -- and the mean-point guard's query (model_opt.py:59-62) -- has unique nearest neighbours in both directions: any correct
+    implementation must reproduce these numbers and decisions, whatever its tie rule."""
+    rng = np.random.default_rng(20260930)
+    thresholds = np.linspace(0, 1.0, 2 ** 8)
+    mets, deltas = ['d1_mse', 'd2_mse', 'd2_sum_max', 'd2_sum_mean'], [np.inf, 2.0]
+
+    def unique_nn(a, b):
+        d = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        return bool(((d == d.min(axis=1, keepdims=True)).sum(axis=1) == 1).all() and ((d == d.min(axis=0, keepdims=True)).sum(axis=0) == 1).all())
+
+    out, kept, trials, R = {}, 0, 0, 16
+    while kept < 6:
+        trials += 1
+        a = np.unique(rng.integers(0, R, (int(rng.integers(5, 12)), 3)), axis=0).astype(np.float64)
+        nrm = rng.standard_normal((len(a), 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        x_hat = np.zeros((R, R, R), np.float32)
+        vox = np.unique(np.clip(a[rng.integers(0, len(a), 12)] + rng.integers(-2, 3, (12, 3)), 0, R - 1).astype(int), axis=0)
+        x_hat[tuple(vox.T)] = rng.permutation(np.linspace(0.08, 0.93, len(vox))).astype(np.float32)
+        ok = unique_nn(a, np.round(np.mean(a, axis=0))[None, :])
+        for t in thresholds:
+            b = np.argwhere(x_hat > t).astype(np.float64)
+            if len(b) == 0 or not ok:
+                break
+            ok = unique_nn(a, b)
+        if not ok:
+            continue
+        block = np.hstack([a, nrm])
+        if kept == 3:
+            block = block.astype(np.float32)
+        names, best = model_opt.compute_optimal_thresholds(block, x_hat, thresholds, 64, normals=block[:, 3:6], opt_metrics=mets,
+                                                           max_deltas=deltas, fixed_threshold=False)
+        i = kept
+        out[f's{i}_block'], out[f's{i}_x_hat'] = block, x_hat
+        out[f's{i}_names'], out[f's{i}_best'] = np.array(names), np.array(best, np.int64)
+        keys, vals = None, []
+        for t in range(len(thresholds)):
+            pa = np.argwhere(x_hat > thresholds[t]).astype('float32')
+            if len(pa) == 0:
+                break
+            m = pc_metric.compute_metrics(block[:, :3], pa, 63, p1_n=block[:, 3:6])
+            keys = sorted(m)
+            vals.append([m[k] for k in keys])
+        out[f's{i}_keys'], out[f's{i}_vals'] = np.array(keys), np.array(vals, np.float64)       # [level, key]: every level set of the block
+        kept += 1
+    out['n_cases'] = np.array([kept])
+    out['opt_metrics'], out['max_deltas'] = np.array(mets), np.array(deltas)
+    out['search_trials'] = np.array([trials])
+    np.savez_compressed(os.path.join(OUT, 'model_opt_d2_tiefree.npz'), **out)
+    print('round 5: model_opt_d2_tiefree.npz,', kept, 'tie-free cases out of', trials, 'trials; decisions',
+          [list(map(int, out[f"s{i}_best"])) for i in range(kept)])
+
+
 def main():
     sys.path.insert(0, REF)
     _shims()
+    if '--round5-only' in sys.argv:
+        import model_opt
+        from utils import pc_metric
+        return round5(model_opt, pc_metric)
     if '--round3-only' in sys.argv:
         import model_opt
         from utils import octree_coding, pc_metric
@@ -264,6 +326,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'model_opt.npz'), **mo)
     print('golden fixtures written to', OUT)
     round3(model_opt, pc_metric, octree_coding)
+    round5(model_opt, pc_metric)
 
 
 if __name__ == '__main__':

@@ -214,13 +214,14 @@ def test_adaptive_threshold_path(ctx):
 
 def test_adaptive_search_with_normals_dispatches_per_metric(ctx, monkeypatch):
     """VERDICT r02 item 5 / the reference's real experiment (ev_experiment.yml:47: opt_metrics ['d1_mse', 'd2_mse'] with
-    normals), on the KD-tree dispatch (PCC_D2_HOST=1; since round 4 the default computes D2 on the GPU with a stated tie rule,
-    tests/test_threshold_search_gpu.py): d1_* decisions come from the GPU distance transforms even though normals are present, the
+    normals), on the default dispatch (d2_* tallies from the host KD-tree pool = the reference's neighbour picks; the GPU D2 search
+    is the opt-in of tests/test_threshold_search_gpu.py): d1_* decisions come from the GPU distance transforms even though normals are present, the
     host pool receives 'tally' jobs only (KD-tree neighbour lists for the D2 columns), and every decision equals the in-process
     host search (model_opt.compute_optimal_thresholds, itself pinned by the reference-generated tests/golden/model_opt_d2.npz).
     With d1 metrics only and normals in the input no host job is issued at all."""
     from pcc_geo_cnn_v2_amd import model_opt
-    monkeypatch.setenv('PCC_D2_HOST', '1')
+    monkeypatch.setattr(model_opt, 'D2_SEARCH', None)
+    monkeypatch.delenv('PCC_D2_GPU', raising=False)
     from pcc_geo_cnn_v2_amd.utils.octree_coding import partition_octree
     res = 32
     rng = np.random.default_rng(11)
@@ -256,8 +257,8 @@ def test_adaptive_search_with_normals_dispatches_per_metric(ctx, monkeypatch):
     # d2 only: the D2 tallies from the host pool, merged into the GPU's table
     _, thr2, _, names2, _ = m.encode_block_range(ctx, blocks, 2 * res, with_normals=True, opt_metrics=['d2_mse'], max_deltas=[np.inf])
     assert m.last_host_job_kind == 'tally' and [t[0] for t in thr2] == [t[1] for t in thr]
-    # the default dispatch: no host job at all, the same d1 decisions
-    monkeypatch.delenv('PCC_D2_HOST')
+    # the opt-in GPU D2 search: no host job at all, the same d1 decisions
+    monkeypatch.setattr(model_opt, 'D2_SEARCH', 'gpu')
     before = m.host_search_jobs
     _, thr3, _, names3, _ = m.encode_block_range(ctx, blocks, 2 * res, with_normals=True, opt_metrics=mets, max_deltas=deltas)
     assert m.host_search_jobs == before and names3 == names and [(t[0], t[2]) for t in thr3] == [(t[0], t[2]) for t in thr]

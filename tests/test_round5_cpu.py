@@ -112,3 +112,53 @@ def test_trace_summary_reports_the_steady_state_not_the_first_launch(tmp_path):
     assert k['outlier'] and 362_000 < k['median'] < 364_000 and 362_000 < k['trimmed'] < 364_000 and k['avg'] > 800_000
     assert not st[('small', '512')]['outlier']
     assert 'max > 10 x median' in text and '1.46 ms/step' in text          # (64 x 363.3 us + 16 x 3 us) / 16 steps
+
+
+def test_tie_free_d2_fixture_pins_the_host_search_to_the_reference():
+    """tests/golden/model_opt_d2_tiefree.npz (make_golden.py --round5-only: the REFERENCE's compute_optimal_thresholds and
+    compute_metrics on six sparse blocks whose level sets -- all of them -- and mean-point query have unique nearest neighbours in both
+    directions).  Without ties the reference's d2_* numbers do not depend on scipy's traversal: the host restatement must give the
+    same decisions for every (metric, max_delta) and the same metric values at EVERY level set; so must the brute-force
+    lowest-(x,y,z) restatement the GPU kernel is tested against (oracle.search_tallies_lowest_index)."""
+    from oracle import oracle as O
+    from pcc_geo_cnn_v2_amd import model_opt
+    from pcc_geo_cnn_v2_amd.utils import pc_metric as PM
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'model_opt_d2_tiefree.npz'))
+    thr = np.linspace(0, 1.0, 256)
+    mets, deltas = [str(m) for m in g['opt_metrics']], [float(d) for d in g['max_deltas']]
+    n = int(g['n_cases'][0])
+    assert n >= 6
+    seen = set()
+    for i in range(n):
+        blk, xh = g[f's{i}_block'], g[f's{i}_x_hat']
+        assert all(O.tie_free(blk, xh, thr))
+        names, best = model_opt.compute_optimal_thresholds(blk, xh, thr, 64, normals=blk[:, 3:6], opt_metrics=mets, max_deltas=deltas)
+        assert names == [str(x) for x in g[f's{i}_names']] and best == [int(b) for b in g[f's{i}_best']], i
+        seen.update(best)
+        keys, want = [str(k) for k in g[f's{i}_keys']], g[f's{i}_vals']
+        tallies, mean_tally = model_opt.host_threshold_stats(blk, xh, thr, blk[:, 3:6])
+        brute = O.search_tallies_lowest_index(blk, xh, thr)
+        assert tallies.shape == brute.shape == (want.shape[0], 5)
+        # (the brute-force restatement rounds the normals to float32 like the GPU path: 1e-6; the host path computes in the block's dtype)
+        assert np.array_equal(tallies[:, :3], brute[:, :3]) and np.allclose(tallies[:, 3:], brute[:, 3:], rtol=1e-6, atol=1e-300)
+        for src, rtol in ((tallies, 1e-6 if blk.dtype != np.float64 else 1e-12), (brute, 1e-6)):
+            table = PM.metrics_table(len(blk), src, 63)
+            got = np.array([[table[k][t] for k in keys] for t in range(len(src))])
+            np.testing.assert_allclose(got, want, rtol=rtol)
+        # the same decisions from the table form, with the lexicographic mean-point guard of the GPU path
+        assert model_opt.select_thresholds_from_stats(len(blk), brute, model_opt.mean_point_tally(blk, True), 256, 64, mets, deltas)[1] == best
+    assert 255 in seen and 0 in seen and len(seen) >= 8          # guards fire, d1 and d2 disagree: the fixture decides something
+
+
+def test_mean_point_guard_takes_the_lowest_xyz_whatever_the_storage_order():
+    """mean_point_tally used the lowest ARRAY index among equidistant original points; the GPU path's rule is the lowest
+    (x, y, z).  A block stored in another order must give the same tally."""
+    from pcc_geo_cnn_v2_amd import model_opt
+    a = np.array([[0, 0, 0], [2, 0, 0], [0, 2, 0], [2, 2, 0], [1, 1, 4]], np.float64)       # mean (1, 1, 0.8) -> (1, 1, 1): four equidistant points
+    nrm = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [0, 1, 1]], np.float64)
+    blk = np.hstack([a, nrm])
+    want = model_opt.mean_point_tally(blk, True)
+    for perm in ([3, 2, 1, 0, 4], [4, 1, 3, 0, 2], [2, 4, 0, 3, 1]):
+        assert np.array_equal(model_opt.mean_point_tally(blk[perm], True), want), perm
+    d = (np.array([1.0, 1.0, 1.0]) - a[0]) @ nrm[0]                                          # the neighbour is (0, 0, 0): lowest (x, y, z)
+    assert np.isclose(want[4], d * d)

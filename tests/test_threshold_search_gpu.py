@@ -142,6 +142,7 @@ def test_d2_search_against_the_reference_fixtures_and_tie_free_cases(ctx, oracle
     g = np.load(os.path.join(G, 'model_opt_d2.npz'), allow_pickle=True)
     thresholds = np.linspace(0, 1.0, 256)
     mets, deltas = [str(m) for m in g['opt_metrics']], [float(d) for d in g['max_deltas']]
+    differing = []
     for i in range(int(g['n_cases'][0])):
         blk, xh = g[f's{i}_block'], g[f's{i}_x_hat']
         tallies = model_opt.d12_tallies_gpu(ctx, [blk], torch.from_numpy(xh[None]).to(ctx.device), thresholds)[0]
@@ -158,6 +159,12 @@ def test_d2_search_against_the_reference_fixtures_and_tie_free_cases(ctx, oracle
         assert names == [str(n) for n in g[f's{i}_names']]
         for k, (mine, theirs) in enumerate(zip(best[0], [int(b) for b in g[f's{i}_best']])):
             assert mine == theirs or (names[k].startswith('d2_') and not all(free)), (i, names[k], mine, theirs)
+            if mine != theirs:
+                differing.append((i, names[k], theirs, mine))
+    # not "may differ where tied" but WHICH decisions the lowest-(x,y,z) rule moves on these fixtures (reference
+    # index -> GPU index; tools/d2_tie_table.py prints the table of DESIGN.md 3.8) -- a regression cannot hide behind `not all(free)`
+    assert differing == [(0, 'd2_mse_inf', 198, 218), (0, 'd2_sum_max_inf', 198, 217), (0, 'd2_mse_2.0', 198, 218), (0, 'd2_sum_max_2.0', 198, 217),
+                         (2, 'd2_sum_max_inf', 233, 232), (2, 'd2_sum_max_2.0', 233, 232)], differing
     # (b) tie-free cases: a handful of scattered points against a handful of scattered decoded voxels
     rng = np.random.default_rng(2024)
     R, kept = 16, 0
@@ -179,9 +186,38 @@ def test_d2_search_against_the_reference_fixtures_and_tie_free_cases(ctx, oracle
     assert kept >= 20, kept
 
 
+def test_gpu_d2_search_reproduces_the_reference_where_no_tie_rule_is_involved(ctx, oracle):
+    """tests/golden/model_opt_d2_tiefree.npz: six sparse blocks on which the REFERENCE's compute_optimal_thresholds / compute_metrics
+    (imported by make_golden.py --round5-only) never meet equidistant neighbours -- not at any level set, not in the mean-point guard.
+    The GPU search (nearest-index transforms + the lexicographic guard) must give every one of the reference's 8 decisions per block and
+    its metric values at EVERY level set (D1 exactly; D2 to the float32 rounding of the normals): at least these reference D2 decisions are
+    pinned end to end."""
+    from pcc_geo_cnn_v2_amd.utils import pc_metric as PM
+    g = np.load(os.path.join(G, 'model_opt_d2_tiefree.npz'))
+    thresholds = np.linspace(0, 1.0, 256)
+    mets, deltas = [str(m) for m in g['opt_metrics']], [float(d) for d in g['max_deltas']]
+    decided = 0
+    for i in range(int(g['n_cases'][0])):
+        blk, xh = g[f's{i}_block'], g[f's{i}_x_hat']
+        assert all(oracle.tie_free(blk, xh, thresholds))
+        tallies = model_opt.d12_tallies_gpu(ctx, [blk], torch.from_numpy(xh[None]).to(ctx.device), thresholds)[0]
+        keys, want = [str(k) for k in g[f's{i}_keys']], g[f's{i}_vals']
+        assert len(tallies) == len(want)
+        table = PM.metrics_table(len(blk), tallies, 63)
+        got = np.array([[table[k][t] for k in keys] for t in range(len(tallies))])
+        d1 = [j for j, k in enumerate(keys) if k.startswith('d1_')]
+        assert np.allclose(got[:, d1], want[:, d1], rtol=1e-12 if blk.dtype == np.float64 else 1e-6)        # (the float32 block: the reference rounds there)
+        assert np.allclose(got, want, rtol=2e-6), (i, np.abs(got / want - 1).max())
+        names, best = model_opt.decide_from_tallies([blk], [tallies], len(thresholds), 64, mets, deltas, gpu_d2=True)
+        assert names == [str(n) for n in g[f's{i}_names']]
+        assert best[0] == [int(b) for b in g[f's{i}_best']], (i, best[0], list(g[f's{i}_best']))
+        decided += sum(n.startswith('d2_') for n in names)
+    assert decided >= 36
+
+
 def test_adaptive_encode_with_d2_metrics_issues_no_host_job(ctx, monkeypatch):
     """compress_blocks with ['d1_mse', 'd2_mse'] and normals (the reference's experiment, src/ev_experiment.yml:47): everything on
-    the GPU (no worker-pool job); PCC_D2_HOST=1 restores the KD-tree pool, whose decisions may differ only through ties."""
+    the GPU with --d2_search gpu (no worker-pool job); the default KD-tree pool's decisions may differ only through ties."""
     from pcc_geo_cnn_v2_amd.model_configs import ModelConfigType
     from pcc_geo_cnn_v2_amd import init_checkpoint
     rng = np.random.default_rng(5)
@@ -194,9 +230,10 @@ def test_adaptive_encode_with_d2_metrics_issues_no_host_job(ctx, monkeypatch):
         nr = rng.standard_normal((len(b), 3)); nr /= np.linalg.norm(nr, axis=1, keepdims=True)
         blocks.append(np.hstack([b, nr]))
     model.host_search_jobs = 0
+    monkeypatch.setattr(model_opt, 'D2_SEARCH', 'gpu')
     out = model.encode_block_range(ctx, blocks, 32, with_normals=True, opt_metrics=['d1_mse', 'd2_mse'], max_deltas=[np.inf])
     assert model.host_search_jobs == 0 and out[3] == ['d1_mse_inf', 'd2_mse_inf']
-    monkeypatch.setenv('PCC_D2_HOST', '1')
+    monkeypatch.setattr(model_opt, 'D2_SEARCH', None)            # the default: D2 tallies from the host KD-tree pool
     host = model.encode_block_range(ctx, blocks, 32, with_normals=True, opt_metrics=['d1_mse', 'd2_mse'], max_deltas=[np.inf])
     assert model.host_search_jobs == len(blocks)
     assert out[0] == host[0] and [t[0] for t in out[1]] == [t[0] for t in host[1]]          # strings and the d1 decisions are the same

@@ -2,7 +2,8 @@
 c3p, with normals -- the reference's experiment setting opt_metrics ['d1_mse', 'd2_mse'] (ev_experiment.yml:47), and d1 only.
   round 2: any normals -> every metric on the host KD-tree pool ('decide' jobs);
   round 3: d1_* from the GPU distance transforms, only the D2 tallies from the host pool ('tally' jobs, B->A neighbours queried once);
-  round 4: d2_* on the GPU as well (nearest-index transforms, stated tie rule); PCC_D2_HOST=1 = the round-3 dispatch."""
+  round 4: d2_* on the GPU as well (nearest-index transforms, stated tie rule);
+  round 5: that is the OPT-IN (--d2_search gpu / PCC_D2_GPU=1); the default is the round-3 dispatch again (tools/d2_tie_table.py: why)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -35,13 +36,14 @@ run(['d1_mse'])                                      # warm-up (kernels)
 run(['d1_mse', 'd2_mse'])
 for mets in (['d1_mse'], ['d1_mse', 'd2_mse']):
     model.host_search_jobs = 0
+    model_opt.D2_SEARCH = 'gpu'
     t_new, thr_new = run(mets)
     jobs_new = model.host_search_jobs
-    os.environ['PCC_D2_HOST'] = '1'                  # round-3 dispatch: D2 tallies from the host KD-tree pool
+    model_opt.D2_SEARCH = 'kdtree'                   # default dispatch: D2 tallies from the host KD-tree pool
     run(mets) if mets[-1].startswith('d2') and 'warm' not in globals() else None
     globals()['warm'] = True
     t_r3, thr_r3 = run(mets)
-    del os.environ['PCC_D2_HOST']
+    model_opt.D2_SEARCH = None
     same_d1 = [a[0] for a in thr_new] == [a[0] for a in thr_r3]
     differ = sum(a != b for a, b in zip(thr_new, thr_r3))
     print(f'{mets}: round 4 (all on the GPU, {jobs_new} host jobs) {t_new:.2f} s / cloud; round-3 dispatch (D2 on the host KD-tree pool) {t_r3:.2f} s / cloud, '
