@@ -30,7 +30,7 @@ from .entropy_models import EntropyBottleneck, GaussianConditional, scale_table
 from .model_opt import d1_tallies_gpu, d12_tallies_gpu, d2_on_gpu, decide_from_tallies, gpu_search_supported, metric_names
 from .model_transforms import TransformType
 from .utils.octree_coding import departition_octree
-from .utils.pc_metric import cloud_metrics_batch
+from .utils.pc_metric import cloud_metrics_batch, finish_metrics
 
 logger = logging.getLogger(__name__)
 
@@ -562,28 +562,41 @@ class CompressionModel:
         n_m = len(max_deltas) * len(opt_metrics)
         if names is None or not len(blocks[lo:hi]):
             names = metric_names(opt_metrics, max_deltas)
-        # (1) one int64 row per block: string lengths, threshold index and candidate point count per metric
-        rows = np.zeros((hi - lo, n_str + 2 * n_m), np.int64)
-        for j in range(hi - lo):
-            rows[j, :n_str] = [len(x) for x in strings_l[j]]
-            rows[j, n_str:n_str + n_m] = thr_l[j][:n_m]
-            rows[j, n_str + n_m:] = [len(x) for x in xhat_l[j][:n_m]]
-        per_rank = sharding.shard_sizes(len(blocks), world)      # known to every rank: no size exchange anywhere below
-        table = sharding.all_gather_rows(rows, counts=per_rank)
-        assert table.shape[0] == len(blocks)
-        first = np.concatenate([[0], np.cumsum(per_rank)])
-        # (2) the strings: one padded uint8 gather to rank 0 (payload sizes follow from the table)
-        blobs = sharding.gather_bytes(b''.join(x for ss in strings_l for x in ss),
-                                      counts=[int(table[first[r]:first[r + 1], :n_str].sum()) for r in range(world)])
-        # (3) D1/D2 of every candidate from per-rank partial tallies (one MIN + one SUM all_reduce for all candidates); the
-        # selection is replicated
+        # (1) D1/D2 of every candidate (select_best_per_opt_metric, src/model_types.py:128-176) from per-rank partial tallies: ONE
+        # all_reduce(MIN) of `d2 * world + rank` over candidates x original points decides which rank's decoded point is nearest to every
+        # original point (it stays an all_reduce: the keys are 8 B per input point and candidate, an all_gather would move them
+        # `world` times); every rank then tallies what it owns -- 5 doubles per candidate, which ride in the row all_gather below
         origins = block_origins(binstr, [0, 0, 0], [resolution] * 3, level)[lo:hi]
         p1, p1_n = points[:, :3], get_normals_if(points, with_normals)
         cand_global = []
         for m in range(n_m):
             parts = [np.asarray(xhat_l[j][m], np.float64).reshape(-1, 3) + np.asarray(origins[j], np.float64) for j in range(hi - lo)]
             cand_global.append(np.vstack(parts) if parts else np.zeros((0, 3)))
-        cand_metrics = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, cKDTree(p1), sharding.RankGroup())
+        part_tallies, have = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, cKDTree(p1), sharding.RankGroup(), partial=True)
+        # (2) ONE all_gather of int64 rows: per block the string lengths, threshold index and candidate point count per metric; per rank
+        # T more rows that carry the bit patterns of its partial tallies (summed below in rank order: every rank gets the same doubles)
+        width = n_str + 2 * n_m
+        T = -(-part_tallies.size // width)
+        rows = np.zeros((hi - lo + T, width), np.int64)
+        for j in range(hi - lo):
+            rows[j, :n_str] = [len(x) for x in strings_l[j]]
+            rows[j, n_str:n_str + n_m] = thr_l[j][:n_m]
+            rows[j, n_str + n_m:] = [len(x) for x in xhat_l[j][:n_m]]
+        rows[hi - lo:].reshape(-1)[:part_tallies.size] = np.ascontiguousarray(part_tallies, np.float64).reshape(-1).view(np.int64)
+        per_rank = sharding.shard_sizes(len(blocks), world)      # known to every rank: no size exchange anywhere below
+        gathered = sharding.all_gather_rows(rows, counts=[n + T for n in per_rank])
+        ends = np.cumsum([n + T for n in per_rank])
+        table = np.concatenate([gathered[e - n - T:e - T] for e, n in zip(ends, per_rank)], 0)
+        tallies = np.zeros_like(part_tallies, dtype=np.float64)
+        for e in ends:
+            tallies += gathered[e - T:e].reshape(-1)[:part_tallies.size].view(np.float64).reshape(part_tallies.shape)
+        assert table.shape[0] == len(blocks)
+        first = np.concatenate([[0], np.cumsum(per_rank)])
+        # (3) the strings: one padded uint8 gather to rank 0 (payload sizes follow from the table)
+        blobs = sharding.gather_bytes(b''.join(x for ss in strings_l for x in ss),
+                                      counts=[int(table[first[r]:first[r + 1], :n_str].sum()) for r in range(world)])
+        # the selection is replicated: every rank holds the summed tallies
+        cand_metrics = finish_metrics(len(p1), tallies, have, resolution - 1, p1_n is not None)
         metadata = [{'idx': m, 'metrics': met} for _, m, met in rank_candidates(names, cand_metrics)]
         # (4) the reconstruction of the selected candidates on rank 0 (only for --dec_files / --debug)
         if need_points:

@@ -6,16 +6,19 @@ RCCL/xGMI) codes a contiguous range of the Morton-ordered block list with replic
 ranks at the end is small and typed -- no pickled Python objects, so a C-ABI caller can reproduce it.  The shard sizes
 are a pure function of (n_blocks, world) (`shard_range`), so no size exchange is needed:
 
-  encoder (compress_blocks), 4 collectives per cloud (+1 per selected candidate with --dec_files / --debug):
-  1. ONE `all_gather` of a fixed-width int64 row per block (string lengths, threshold indices, candidate point counts);
-     every rank derives every other rank's payload sizes from it;
-  2. ONE padded uint8 `gather` of the concatenated strings to rank 0 (tens of KB per cloud), which assembles the same
+  encoder (compress_blocks), 3 collectives per cloud (+1 per selected candidate with --dec_files / --debug; round 4: 4):
+  1. the D1/D2 numbers of `select_best_per_opt_metric` (src/model_types.py:128-176) for ALL candidates start from ONE
+     `all_reduce(MIN)` over candidates x original points (`RankGroup.claim`: which rank holds the nearest decoded point of
+     every original point); every rank then tallies the pairs it owns (`cloud_metrics_batch(..., partial=True)`);
+  2. ONE `all_gather` of fixed-width int64 rows: per block (string lengths, threshold indices, candidate point counts) --
+     every rank derives every other rank's payload sizes from it -- plus, per rank, the bit patterns of its partial tallies
+     (candidates x 5 doubles), summed by every rank in rank order (round 4 spent an `all_reduce(SUM)` on them);
+  3. ONE padded uint8 `gather` of the concatenated strings to rank 0 (tens of KB per cloud), which assembles the same
      file a single-GPU run writes;
-  3. the D1/D2 numbers of `select_best_per_opt_metric` (src/model_types.py:128-176) for ALL candidates from per-rank
-     partial tallies (`utils.pc_metric.cloud_metrics_batch` with a `RankGroup`): ONE `all_reduce(MIN)` over
-     candidates x original points + ONE `all_reduce(SUM)` of candidates x 5 scalars;
   4. only when the caller wants the reconstruction on rank 0 (`--dec_files`, `--debug`): one `gather` of the selected
      candidate's decoded float32 points.
+  The MIN stays an all_reduce on purpose: its keys are 8 B per input point and candidate, and folding them into the all_gather
+  too (SURVEY.md 8e's "single gather") would move them `world` times for one latency saved.
   decoder (decompress_blocks), 2 collectives: one `all_gather` of the per-block point counts, one `gather` of the points.
 Everything is latency-bound except (3)'s MIN over N_A int64 keys per candidate (8 MB per million input points).
 `all_gather_rows` / `gather_rows` / `gather_bytes` without `counts` (ragged input of unknown size) prepend one small

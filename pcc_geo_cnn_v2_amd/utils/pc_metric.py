@@ -128,7 +128,7 @@ class SingleProcess:
         return tallies
 
 
-def cloud_metrics_batch(p1, p2_locals, r, p1_n=None, t1=None, comm=None):
+def cloud_metrics_batch(p1, p2_locals, r, p1_n=None, t1=None, comm=None, partial=False):
     """D1 (and, with normals `p1_n`, D2) metrics between the original cloud p1 (replicated on every rank) and each of several
     candidate decoded clouds, candidate m = union over ranks of `p2_locals[m]`.  Returns one reference-style dictionary per
     candidate (None where the decoded cloud is empty on every rank).  Two collectives for ALL candidates (one MIN, one SUM),
@@ -149,9 +149,15 @@ def cloud_metrics_batch(p1, p2_locals, r, p1_n=None, t1=None, comm=None):
     for m, ((p2, to_b, to_a, _), mine) in enumerate(zip(links, owned)):
         if mine is not None:
             tallies[m] = pair_tally(p1, p2, to_b, to_a, p1_n, None if mine.all() else mine)
-    tallies = comm.total(tallies)
-    groups = GROUPS if p1_n is not None else GROUPS[:1]
-    return [metrics_table(len(p1), tallies[m], r, groups) if owned[m] is not None else None for m in range(len(links))]
+    if partial:     # the caller sums the per-rank tallies itself (they ride in a collective it issues anyway) and finishes with finish_metrics
+        return tallies, [o is not None for o in owned]
+    return finish_metrics(len(p1), comm.total(tallies), [o is not None for o in owned], r, p1_n is not None)
+
+
+def finish_metrics(n_a, tallies, have, r, with_normals):
+    """Reference-style metric dictionaries from the (globally summed) tallies of cloud_metrics_batch(..., partial=True)."""
+    groups = GROUPS if with_normals else GROUPS[:1]
+    return [metrics_table(n_a, tallies[m], r, groups) if have[m] else None for m in range(len(tallies))]
 
 
 def compute_metrics(p1, p2, r, p1_n=None, t1=None):

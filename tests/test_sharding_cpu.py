@@ -72,8 +72,11 @@ def test_two_rank_sharded_compress_equals_single_process(tmp_path):
                     assert np.isclose(ma[k], v, rtol=0.05), (k, ma[k], v)
     # the number of collectives DESIGN.md §6 states: no size exchanges (shard sizes are a function of (n_blocks, world))
     for r in range(2):
-        assert two[r]['calls_compress'] == ['all_gather', 'gather', 'all_reduce', 'all_reduce', 'gather']   # last: --dec_files points
-        assert two[r]['calls_two'] == ['all_gather', 'gather', 'all_reduce', 'all_reduce']                 # 2 candidates, need_points=False
+        # round 5: the SUM of the candidates' partial tallies rides in the row all_gather: 3 collectives per cloud,
+        # whatever the number of candidates; the MIN over candidates x original points stays an all_reduce (8 B per point: an all_gather
+        # would move it `world` times)
+        assert two[r]['calls_compress'] == ['all_reduce', 'all_gather', 'gather', 'gather']   # last: --dec_files points
+        assert two[r]['calls_two'] == ['all_reduce', 'all_gather', 'gather']                 # 2 candidates, need_points=False
         assert two[r]['calls_dec'] == ['all_gather', 'gather']
     assert one[0]['calls_compress'] == one[0]['calls_two'] == one[0]['calls_dec'] == []
     # decoder: all points on rank 0, in block order
