@@ -92,6 +92,10 @@ void pcc_tr2m_bf16_pack(int Cin, int Cout, const float* w_tr2g, float* out);
 bool pcc_tr2m_bf16_covers(const pcc_conv_desc* d);
 int pcc_conv_tr2m_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
                        hipStream_t st);
+// the march in the fp16 mode (conv_tr2m_f16.hip, round 5): fp32 input, fp16 MFMA, fp16 output (PCC_CONV_F16 | PCC_CONV_OUT16), 32 -> 16 and 64 -> 32
+bool pcc_tr2m_f16_covers(const pcc_conv_desc* d);
+int pcc_conv_tr2m_f16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_tr2g, const float* bias, void* out,
+                      hipStream_t st);
 // fp16-storage k3 stride-1 kernel for Cin = Cout in {16, 32} (conv_f16.hip), PCC_CONV_IN16 layers
 bool pcc_f16_eligible(const pcc_conv_desc* d);
 size_t pcc_f16_packed_bytes(int C);

@@ -1910,6 +1910,9 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
         PCC_CASE_FWD(16, 32, 3, 2) PCC_CASE_FWD(32, 64, 3, 2) PCC_CASE_FWD(64, 64, 3, 2)
         PCC_CASE_FWD(32, 32, 3, 2) PCC_CASE_FWD(32, 32, 5, 2)
     } else if (p.kind == K_TR2) {
+        // fp16 mode, fp16 hand-over: the z march with fp16 MFMAs (conv_tr2m_f16.hip, round 5); shape-only rule, PCC_NO_TR2M=1: the tiled kernel (A/B)
+        if (k == 3 && d->impl == PCC_IMPL_AUTO && !ctx->num(PCC_NUM_NO_TR2M) && pcc_tr2m_f16_covers(d))
+            return pcc_conv_tr2m_f16(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
         // 64 -> 32 / 64 -> 64: split-bf16 operands on the bf16 MFMA pipe (conv_tr2_split_kernel); shape-only rule, PCC_NO_SPLIT=1 /
         // PCC_NO_SPLIT_TR2=1: the exact-fp32 kernels below (A/B)
         if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) &&

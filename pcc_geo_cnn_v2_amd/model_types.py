@@ -290,6 +290,15 @@ class CompressionModel:
             self._host_search_pool = pool = HostSearchPool(want)
         return pool
 
+    def _helper_thread(self, name):
+        """Single helper threads of roundtrip_stream besides the encoder's: 'ydec' (the decoder's y range-decode), 'gather' (point lists
+        to the host).  One thread each: the jobs of a kind complete in submission order."""
+        pools = self.__dict__.setdefault('_helper_pools', {})
+        if name not in pools:
+            from concurrent.futures import ThreadPoolExecutor
+            pools[name] = ThreadPoolExecutor(max_workers=1, thread_name_prefix=f'pcc-{name}')
+        return pools[name]
+
     def _coder_thread(self):
         """One helper thread for host range-coder work that may overlap the calling thread's (roundtrip_stream)."""
         if getattr(self, '_coder_pool', None) is None:
@@ -638,15 +647,24 @@ class CompressionModel:
         q_b, q_g = [], []
 
         def stage_b(item):
-            strings, cnt_e, st, dhw, B = item
-            dec = self._decode_phase_b(ctx, st, dhw, False, thr=self._thr_tensor(ctx, [thr_idx] * B))
+            strings, cnt_e, st, dhw, B, yfut = item
+            kw = {} if yfut is None else {'host': yfut.result()}
+            dec = self._decode_phase_b(ctx, st, dhw, False, thr=self._thr_tensor(ctx, [thr_idx] * B), **kw)
             xyz_d, cnt_d = dec['xyz'], dec['counts']
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(ctx.device))
-            return strings, cnt_e, xyz_d, cnt_d, ready
+            item_g = (strings, cnt_e, xyz_d, cnt_d, ready)
+            # (round 5) few long streams per chunk: the gather (counts to the host, pack, 10 MB of points per 8-block chunk of 128^3 blocks:
+            # 0.9 ms of blocking copies) runs on a helper thread too; results are still yielded in order
+            return self._helper_thread('gather').submit(stage_g_work, item_g) if threaded else item_g
 
         def stage_g(item):
+            return item.result() if threaded else stage_g_work(item)
+
+        def stage_g_work(item):
             strings, cnt_e, xyz_d, cnt_d, ready = item
+            if threaded:
+                torch.cuda.set_device(ctx.device)
             pts = self._gather_points(xyz_d, cnt_d, ctx, ready) if gather else None
             with torch.cuda.stream(self._side_stream(ctx)):     # never a blocking copy on the main stream
                 self._side_stream(ctx).wait_event(ready)
@@ -661,7 +679,10 @@ class CompressionModel:
             enc, dhw, B = item
             strings = enc['strings'].result()
             st = self._decode_phase_a(ctx, strings, dhw)
-            q_b.append((strings, enc['counts'], st, dhw, B))
+            # (round 5) the y range-decode of this chunk -- host work only -- starts now on a helper thread and is collected one iteration
+            # later by stage_b, when both coders fit the usable cores side by side (the rule of the encoder's helper thread below)
+            yfut = self._helper_thread('ydec').submit(self._decode_phase_b_host, st) if threaded and hasattr(self, '_decode_phase_b_host') else None
+            q_b.append((strings, enc['counts'], st, dhw, B, yfut))
             if len(q_b) > 1:
                 q_g.append(stage_b(q_b.pop(0)))
 
@@ -672,9 +693,12 @@ class CompressionModel:
         # stream, so at 128^3 one chunk's y streams cost the host milliseconds -- while this thread range-DECODES an older chunk
         # and feeds the GPU; the library calls release the GIL.
         q_a, k = [], 0
+        threaded = None
         trace = os.environ.get('PCC_STAGE_TIMES')          # host time per pipeline stage and iteration (ms), to stderr
         for x in dense_chunks:
             B, dhw = x.shape[0], tuple(x.shape[1:4])
+            if threaded is None:
+                threaded = 2 * B <= _usable_cores() and not os.environ.get('PCC_NO_HELPER_THREADS')
             t0 = time.perf_counter()
             enc = self._encode_batch(ctx, x, False, thr=self._thr_tensor(ctx, [thr_idx] * B), slot=k % 3)
             # (only when both coders fit the usable cores side by side: with 32 streams per call on a 16-core container the two
@@ -1012,15 +1036,25 @@ class CompressionModelV2(CompressionModel):
             ev.record(side)
         return dict(strings=strings, idx_h=idx_h, ev=ev, z_hat=z_hat, sigma=sigma, idx=idx, zsym_h=zsym_h)
 
-    def _decode_phase_b(self, ctx, st, dhw, debug, thr=None):
-        """(y_string, indexes) -GC.decompress-> y_hat -S-> x_hat [-> thresholded points]."""
+    def _decode_phase_b_host(self, st):
+        """The host part of phase b: wait for the CDF-row indexes, range-decode the y strings into a pinned buffer.  No GPU work is
+        enqueued here, so roundtrip_stream may run it on a helper thread (the coder is sequential per stream: 2 ms per 8-block chunk
+        of 128^3 blocks) while the calling thread keeps feeding the device."""
         gc = self.conditional_bottleneck
         strings, idx_h = st['strings'], st['idx_h']
         B = len(strings)
         st['ev'].synchronize()
         ysym_h, ysym_release = self._pinned.ring('dec_ysym', idx_h.shape, _host_dtypes()[0])
         n = int(np.prod(idx_h.shape[1:]))
-        packed = self._symbols_to_device(ctx, self._range_decode(gc.table, [s[0] for s in strings], n, idx_h.view(B, -1), 0, ysym_h), ysym_release)
+        return self._range_decode(gc.table, [s[0] for s in strings], n, idx_h.view(B, -1), 0, ysym_h), ysym_release
+
+    def _decode_phase_b(self, ctx, st, dhw, debug, thr=None, host=None):
+        """(y_string, indexes) -GC.decompress-> y_hat -S-> x_hat [-> thresholded points].  host: the result of _decode_phase_b_host when
+        it already ran elsewhere."""
+        strings = st['strings']
+        B = len(strings)
+        ysym, ysym_release = self._decode_phase_b_host(st) if host is None else host
+        packed = self._symbols_to_device(ctx, ysym, ysym_release)
         codec = self._codec(ctx)
         if codec is not None:                      # unpack -> dequantise -> synthesis (-> threshold + compaction) in one ABI call
             t = ops.codec_decode_main(ctx, codec, None, dhw, thr, packed=packed, channels_first=self.data_format == 'channels_first')
