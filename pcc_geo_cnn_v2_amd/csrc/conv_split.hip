@@ -105,9 +105,14 @@ struct SplitCfg {
     static constexpr int NYG = TY / (R * LPR);          // y groups (of R rows) of the tile
     static constexpr int NW = TZ * NYG * NCG, NT = NW * 64;
     static constexpr int LZ = TZ + 2, LY = TY + 2, LX = TXW + 2;
+    // Line pitch of the LDS tile in voxels.  TXW = 8 (round 5): an MFMA row is TWO lines, and with the natural pitch of 10 voxels the second
+    // line starts 100 bank quads = 4 (mod 16) behind the first: the ds_read_b128 lane groups {0-3, 12-15, 20-27} ... (MI355X_MICROARCH.md, LDS)
+    // then hit {0,4,10,14} with lanes 0-3 and {12,6,0,10} with lanes 12-15 -- measured SQ_LDS_BANK_CONFLICT = 0.50 of the LDS cycles.  A pitch of
+    // 16 voxels (160 quads = 0 mod 16) puts the second line on the complementary quads {2,6,8,12} / {1,5,11,15}: conflict-free for every tap.
+    static constexpr int LXP = TXW == 8 ? 16 : LX;
     static constexpr int VS = 40;                       // dwords per voxel in LDS: B1 (16) + B2 (16) + 8 pad
-    static constexpr int NV = LZ * LY * LX;
-    static constexpr int LDS_BYTES = NV * VS * 4;
+    static constexpr int NV = LZ * LY * LX;             // staged voxels
+    static constexpr int LDS_BYTES = LZ * LY * LXP * VS * 4;
     static constexpr int ITEMS = ((NV * 4 + NT - 1) / NT + 1) & ~1;      // (voxel, cin quad) items per thread, even: split two at a time
     static constexpr int RING = 3;                      // weight ring depth (taps); 27 % RING == 0
     static_assert(TY % (R * LPR) == 0 && NCT % CTW == 0 && 27 % RING == 0 && ITEMS <= 26 && (TXW == 16 || TXW == 8), "bad tile");
@@ -132,8 +137,8 @@ conv_k3s1_split_kernel(SplitArgs a) {
     const int ct0 = (wave % C::NCG) * CTW;               // first cout tile of this wave
     const int w_yg = (wave / C::NCG) % C::NYG, w_z = wave / C::NCG / C::NYG;
     const int ly0 = w_yg * R * C::LPR + v / TXW, lx0 = v % TXW;      // row i of the wave: line ly0 + i * LPR
-    const unsigned* lbase = lds + ((w_z * C::LY + ly0) * C::LX + lx0) * C::VS + cq * 4;
-    constexpr int ROW_OFF = C::LPR * C::LX * C::VS;
+    const unsigned* lbase = lds + ((w_z * C::LY + ly0) * C::LXP + lx0) * C::VS + cq * 4;
+    constexpr int ROW_OFF = C::LPR * C::LXP * C::VS;
 
     f32x4 acc[R][CTW];
 #pragma unroll
@@ -146,15 +151,17 @@ conv_k3s1_split_kernel(SplitArgs a) {
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(C::NG * NTAP * C::NCT) * 2048u);
     const unsigned wlane = lane * 16;
     const int q_last = C::NG * NTAP - 1;
-    auto tap_off = [](int kz, int ky, int kx) { return ((kz * C::LY + ky) * C::LX + kx) * C::VS; };
+    auto tap_off = [](int kz, int ky, int kx) { return ((kz * C::LY + ky) * C::LXP + kx) * C::VS; };
 
     unsigned soff[C::ITEMS];
+    unsigned lw[C::LXP != C::LX ? C::ITEMS : 1];          // LDS dword offset of the item's voxel when the line pitch is padded
 #pragma unroll
     for (int it = 0; it < C::ITEMS; ++it) {
         const int item = it * C::NT + tid;
         const int u = item >> 2, q = item & 3;
         const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
         const int ly = rem / C::LX, lx = rem - ly * C::LX;
+        if constexpr (C::LXP != C::LX) lw[it] = (unsigned)((((lz * C::LY + ly) * C::LXP + lx) * C::VS) + q * 4);
         const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
         const bool ok = (item < C::NV * 4) & (gz >= 0) & (gz < a.D) & (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W);
         soff[it] = ok ? (unsigned)(((gz * a.H + gy) * a.W + gx) * CH + q * 4) * 4u : kOOB;
@@ -166,13 +173,15 @@ conv_k3s1_split_kernel(SplitArgs a) {
             u32x4 p1, p2, q1, q2;
             split_items2(p1, p2, q1, q2, stg[it], stg[it + 1]);
             const int i0 = it * C::NT + tid, i1 = (it + 1) * C::NT + tid;
+            const unsigned o0 = C::LXP != C::LX ? lw[C::LXP != C::LX ? it : 0] : (unsigned)((i0 >> 2) * C::VS + (i0 & 3) * 4);
+            const unsigned o1 = C::LXP != C::LX ? lw[C::LXP != C::LX ? it + 1 : 0] : (unsigned)((i1 >> 2) * C::VS + (i1 & 3) * 4);
             if (i0 < C::NV * 4) {
-                *reinterpret_cast<u32x4*>(lds + (i0 >> 2) * C::VS + (i0 & 3) * 4) = p1;
-                *reinterpret_cast<u32x4*>(lds + (i0 >> 2) * C::VS + 16 + (i0 & 3) * 4) = p2;
+                *reinterpret_cast<u32x4*>(lds + o0) = p1;
+                *reinterpret_cast<u32x4*>(lds + o0 + 16) = p2;
             }
             if (i1 < C::NV * 4) {
-                *reinterpret_cast<u32x4*>(lds + (i1 >> 2) * C::VS + (i1 & 3) * 4) = q1;
-                *reinterpret_cast<u32x4*>(lds + (i1 >> 2) * C::VS + 16 + (i1 & 3) * 4) = q2;
+                *reinterpret_cast<u32x4*>(lds + o1) = q1;
+                *reinterpret_cast<u32x4*>(lds + o1 + 16) = q2;
             }
         }
     };

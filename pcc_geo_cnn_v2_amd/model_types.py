@@ -698,7 +698,7 @@ class CompressionModel:
         for x in dense_chunks:
             B, dhw = x.shape[0], tuple(x.shape[1:4])
             if threaded is None:
-                threaded = 2 * B <= _usable_cores() and not os.environ.get('PCC_NO_HELPER_THREADS')
+                threaded = (2 * B <= _usable_cores() or bool(os.environ.get('PCC_FORCE_HELPER_THREADS'))) and not os.environ.get('PCC_NO_HELPER_THREADS')
             t0 = time.perf_counter()
             enc = self._encode_batch(ctx, x, False, thr=self._thr_tensor(ctx, [thr_idx] * B), slot=k % 3)
             # (only when both coders fit the usable cores side by side: with 32 streams per call on a 16-core container the two

@@ -5,7 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 shutil.copy(glob.glob(os.path.join(src, 'trace', '**', 't_kernel_stats.csv'), recursive=True)[0], os.path.join(dst, f'{tag}_kernel_stats.csv'))
 summary = subprocess.check_output([sys.executable, os.path.join(root, 'tools', 'summarize_trace.py'),
-                                   glob.glob(os.path.join(src, 'trace', '**', 't_kernel_trace.csv'), recursive=True)[0], '6', '24'], text=True)
+                                   glob.glob(os.path.join(src, 'trace', '**', 't_kernel_trace.csv'), recursive=True)[0], '15', '24'], text=True)
 bench = [l for l in open(os.path.join(src, 'bench.log')) if l.startswith('{"metric"')]
 bench_prof = [l for l in open(os.path.join(src, 'bench_profiled.log')) if l.startswith('{"metric"')]
 pmc, dur = {}, []
@@ -35,7 +35,7 @@ out = {'kernel': 'conv_f16_kernel<16> (fp16 storage, v_mfma_f32_16x16x32_f16), C
        'lds_bank_conflict_cycles': pmc.get('SQ_LDS_BANK_CONFLICT', 0), 'raw_counters': pmc}
 json.dump(out, open(os.path.join(dst, f'{tag}_kernel_counters.json'), 'w'), indent=1)
 with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
-    f.write(f'# {tag}: fp16 mode, BASELINE.json configs[4] (NOT the headline precision)\n\n`rocprofv3 --kernel-trace --stats -- python bench.py --workload configs4 --steps 5 --warmup 1` '
+    f.write(f'# {tag}: fp16 mode, BASELINE.json configs[4] (NOT the headline precision)\n\n`rocprofv3 --kernel-trace --stats -- PCC_BENCH_NO_PRIME=1 python bench.py --workload configs4 --steps 10 --warmup 5` (15 steps, all counted)` '
             '(c3p graph, 128^3 blocks, batch 8, encode+decode), per (kernel, grid size):\n\n' + summary + '\n')
     f.write('`__amd_rocclr_copyBuffer` rows above: the pinned device<->host copies of the side streams (symbols, CDF-row indexes, decoded point lists).  '
             'With rocprofv3 attached the runtime executes them as a blit KERNEL on the CUs; without it they go to the SDMA engines '
