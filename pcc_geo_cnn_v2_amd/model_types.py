@@ -571,39 +571,53 @@ class CompressionModel:
         n_m = len(max_deltas) * len(opt_metrics)
         if names is None or not len(blocks[lo:hi]):
             names = metric_names(opt_metrics, max_deltas)
-        # (1) D1/D2 of every candidate (select_best_per_opt_metric, src/model_types.py:128-176) from per-rank partial tallies: ONE
-        # all_reduce(MIN) of `d2 * world + rank` over candidates x original points decides which rank's decoded point is nearest to every
-        # original point (it stays an all_reduce: the keys are 8 B per input point and candidate, an all_gather would move them
-        # `world` times); every rank then tallies what it owns -- 5 doubles per candidate, which ride in the row all_gather below
+        # What crosses ranks (sharding.py).  Per block one int64 row: string lengths, threshold index and candidate point count per metric.
+        # The D1/D2 numbers of every candidate (select_best_per_opt_metric, src/model_types.py:128-176) come from per-rank partial tallies
+        # of the pairs a rank OWNS (its decoded point is the nearest one to an original point: MIN over ranks of `d2 * world + rank`).
         origins = block_origins(binstr, [0, 0, 0], [resolution] * 3, level)[lo:hi]
         p1, p1_n = points[:, :3], get_normals_if(points, with_normals)
         cand_global = []
         for m in range(n_m):
             parts = [np.asarray(xhat_l[j][m], np.float64).reshape(-1, 3) + np.asarray(origins[j], np.float64) for j in range(hi - lo)]
             cand_global.append(np.vstack(parts) if parts else np.zeros((0, 3)))
-        part_tallies, have = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, cKDTree(p1), sharding.RankGroup(), partial=True)
-        # (2) ONE all_gather of int64 rows: per block the string lengths, threshold index and candidate point count per metric; per rank
-        # T more rows that carry the bit patterns of its partial tallies (summed below in rank order: every rank gets the same doubles)
         width = n_str + 2 * n_m
-        T = -(-part_tallies.size // width)
-        rows = np.zeros((hi - lo + T, width), np.int64)
+        rows = np.zeros((hi - lo, width), np.int64)
         for j in range(hi - lo):
             rows[j, :n_str] = [len(x) for x in strings_l[j]]
             rows[j, n_str:n_str + n_m] = thr_l[j][:n_m]
             rows[j, n_str + n_m:] = [len(x) for x in xhat_l[j][:n_m]]
-        rows[hi - lo:].reshape(-1)[:part_tallies.size] = np.ascontiguousarray(part_tallies, np.float64).reshape(-1).view(np.int64)
         per_rank = sharding.shard_sizes(len(blocks), world)      # known to every rank: no size exchange anywhere below
-        gathered = sharding.all_gather_rows(rows, counts=[n + T for n in per_rank])
-        ends = np.cumsum([n + T for n in per_rank])
-        table = np.concatenate([gathered[e - n - T:e - T] for e, n in zip(ends, per_rank)], 0)
-        tallies = np.zeros_like(part_tallies, dtype=np.float64)
-        for e in ends:
-            tallies += gathered[e - T:e].reshape(-1)[:part_tallies.size].view(np.float64).reshape(part_tallies.shape)
-        assert table.shape[0] == len(blocks)
         first = np.concatenate([[0], np.cumsum(per_rank)])
-        # (3) the strings: one padded uint8 gather to rank 0 (payload sizes follow from the table)
-        blobs = sharding.gather_bytes(b''.join(x for ss in strings_l for x in ss),
-                                      counts=[int(table[first[r]:first[r + 1], :n_str].sum()) for r in range(world)])
+        my_strings = b''.join(x for ss in strings_l for x in ss)
+        if 8 * len(p1) * n_m * world <= int(os.environ.get('PCC_KEY_GATHER_MAX_BYTES', 64 << 20)):
+            # TWO collectives per cloud: (1) ONE all_gather of the rows with the MIN keys of all candidates riding as extra
+            # rows (sharding.PiggybackGroup: every rank takes the MIN itself), (2) ONE all_gather of bytes: strings + the partial tallies
+            grp = sharding.PiggybackGroup(rows, per_rank)
+            part_tallies, have = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, cKDTree(p1), grp, partial=True)
+            table = grp.table
+            tb = np.ascontiguousarray(part_tallies, np.float64).tobytes()
+            payloads = sharding.all_gather_bytes(my_strings + tb, counts=[int(table[first[r]:first[r + 1], :n_str].sum()) + len(tb) for r in range(world)])
+            blobs = [p[:len(p) - len(tb)] for p in payloads]
+            tallies = np.zeros_like(part_tallies, dtype=np.float64)
+            for p in payloads:          # rank order: every rank gets the same doubles
+                tallies += np.frombuffer(p[len(p) - len(tb):], np.float64).reshape(part_tallies.shape)
+        else:
+            # a cloud whose keys (8 B per original point and candidate) are too many to move `world` times: THREE collectives -- (1) ONE
+            # all_reduce(MIN) of the keys, (2) ONE all_gather of the rows + T rows with the bit patterns of the partial tallies (summed in
+            # rank order), (3) ONE padded uint8 gather of the strings to rank 0
+            part_tallies, have = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, cKDTree(p1), sharding.RankGroup(), partial=True)
+            T = -(-part_tallies.size // width)
+            send = np.zeros((hi - lo + T, width), np.int64)
+            send[:hi - lo] = rows
+            send[hi - lo:].reshape(-1)[:part_tallies.size] = np.ascontiguousarray(part_tallies, np.float64).reshape(-1).view(np.int64)
+            gathered = sharding.all_gather_rows(send, counts=[n + T for n in per_rank])
+            ends = np.cumsum([n + T for n in per_rank])
+            table = np.concatenate([gathered[e - n - T:e - T] for e, n in zip(ends, per_rank)], 0)
+            tallies = np.zeros_like(part_tallies, dtype=np.float64)
+            for e in ends:
+                tallies += gathered[e - T:e].reshape(-1)[:part_tallies.size].view(np.float64).reshape(part_tallies.shape)
+            blobs = sharding.gather_bytes(my_strings, counts=[int(table[first[r]:first[r + 1], :n_str].sum()) for r in range(world)])
+        assert table.shape[0] == len(blocks)
         # the selection is replicated: every rank holds the summed tallies
         cand_metrics = finish_metrics(len(p1), tallies, have, resolution - 1, p1_n is not None)
         metadata = [{'idx': m, 'metrics': met} for _, m, met in rank_candidates(names, cand_metrics)]

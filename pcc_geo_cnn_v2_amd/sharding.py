@@ -6,19 +6,19 @@ RCCL/xGMI) codes a contiguous range of the Morton-ordered block list with replic
 ranks at the end is small and typed -- no pickled Python objects, so a C-ABI caller can reproduce it.  The shard sizes
 are a pure function of (n_blocks, world) (`shard_range`), so no size exchange is needed:
 
-  encoder (compress_blocks), 3 collectives per cloud (+1 per selected candidate with --dec_files / --debug; round 4: 4):
-  1. the D1/D2 numbers of `select_best_per_opt_metric` (src/model_types.py:128-176) for ALL candidates start from ONE
-     `all_reduce(MIN)` over candidates x original points (`RankGroup.claim`: which rank holds the nearest decoded point of
-     every original point); every rank then tallies the pairs it owns (`cloud_metrics_batch(..., partial=True)`);
-  2. ONE `all_gather` of fixed-width int64 rows: per block (string lengths, threshold indices, candidate point counts) --
-     every rank derives every other rank's payload sizes from it -- plus, per rank, the bit patterns of its partial tallies
-     (candidates x 5 doubles), summed by every rank in rank order (round 4 spent an `all_reduce(SUM)` on them);
-  3. ONE padded uint8 `gather` of the concatenated strings to rank 0 (tens of KB per cloud), which assembles the same
-     file a single-GPU run writes;
-  4. only when the caller wants the reconstruction on rank 0 (`--dec_files`, `--debug`): one `gather` of the selected
+  encoder (compress_blocks), TWO collectives per cloud (+1 per selected candidate with --dec_files / --debug; round 4: 4):
+  1. ONE `all_gather` of fixed-width int64 rows: per block (string lengths, threshold indices, candidate point counts) --
+     every rank derives every other rank's payload sizes from it -- and, riding as extra rows, the keys `d2 * world + rank` of
+     ALL candidates x original points (`PiggybackGroup.claim`): every rank takes the MIN over ranks itself and so knows which
+     rank holds the nearest decoded point of every original point (the D1/D2 numbers of `select_best_per_opt_metric`,
+     src/model_types.py:128-176, are tallied by the owner: `cloud_metrics_batch(..., partial=True)`);
+  2. ONE padded uint8 `all_gather` of (concatenated strings + the rank's partial tallies, candidates x 5 doubles): rank 0 assembles
+     the same file a single-GPU run writes, every rank sums the tallies in rank order (the selection is replicated);
+  3. only when the caller wants the reconstruction on rank 0 (`--dec_files`, `--debug`): one `gather` of the selected
      candidate's decoded float32 points.
-  The MIN stays an all_reduce on purpose: its keys are 8 B per input point and candidate, and folding them into the all_gather
-  too (SURVEY.md 8e's "single gather") would move them `world` times for one latency saved.
+  The keys are 8 B per input point and candidate and an all_gather moves them `world` times: above PCC_KEY_GATHER_MAX_BYTES (64 MB:
+  a million points, one candidate, eight ranks) the MIN stays ONE `all_reduce` (`RankGroup.claim`), the tallies ride in the row
+  all_gather and the strings go to rank 0 with one `gather`: three collectives.
   decoder (decompress_blocks), 2 collectives: one `all_gather` of the per-block point counts, one `gather` of the points.
 Everything is latency-bound except (3)'s MIN over N_A int64 keys per candidate (8 MB per million input points).
 `all_gather_rows` / `gather_rows` / `gather_bytes` without `counts` (ragged input of unknown size) prepend one small
@@ -120,6 +120,19 @@ def gather_bytes(payload, device=None, dst=0, counts=None):
     return [flat[off[r]:off[r + 1]].tobytes() for r in range(world)]
 
 
+def all_gather_bytes(payload, device=None, counts=None):
+    """One byte string per rank -> list of byte strings (rank order) on EVERY rank: one padded uint8 `all_gather` (`counts`: the payload
+    size of every rank, known to all)."""
+    d = _dist()
+    if d is None:
+        return [bytes(payload)]
+    arr = np.frombuffer(bytes(payload), np.uint8)
+    sizes = _row_counts(d, arr.size, counts, _device(d, device))
+    flat = all_gather_rows(arr, device, counts=sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    return [flat[off[r]:off[r + 1]].tobytes() for r in range(d.get_world_size())]
+
+
 def all_reduce(arr, op, device=None):
     """all_reduce of a numpy array ('min' | 'sum'); returns the reduced array on every rank."""
     d = _dist()
@@ -155,6 +168,40 @@ class RankGroup:
 
     def total(self, tallies):
         return all_reduce(tallies, 'sum', self.device)
+
+
+class PiggybackGroup(RankGroup):
+    """RankGroup whose claim() does not spend a collective of its own: the int64 keys `d2 * world + rank` of all candidates ride as extra
+    rows in an all_gather the caller needs anyway (the per-block row table of the sharded encoder), and every rank takes the MIN over
+    ranks itself -- the "single gather" of SURVEY.md 8e.  Moves the keys `world` times (an all_reduce moves them once): the caller uses it
+    when 8 B x candidates x original points x world stays below a bound, else RankGroup.  After claim(): `.table` = the caller's rows
+    of all ranks in rank order."""
+
+    def __init__(self, rows, per_rank_rows, device=None):
+        super().__init__(device)
+        self.rows, self.per_rank_rows, self.table = np.ascontiguousarray(rows, np.int64), [int(n) for n in per_rank_rows], None
+
+    def claim(self, sq_dist_ab, have_points):
+        n_cand = len(sq_dist_ab)
+        big = np.iinfo(np.int64).max
+        keys = np.stack([np.rint(d).astype(np.int64) * self.world + self.rank if h else np.full(len(d), big, np.int64)
+                         for d, h in zip(sq_dist_ab, have_points)]) if n_cand else np.zeros((0, 0), np.int64)
+        width = self.rows.shape[1]
+        K = -(-keys.size // width)
+        send = np.zeros((self.rows.shape[0] + K, width), np.int64)
+        send[:self.rows.shape[0]] = self.rows
+        send[self.rows.shape[0]:].reshape(-1)[:keys.size] = keys.reshape(-1)
+        got = all_gather_rows(send, self.device, counts=[n + K for n in self.per_rank_rows])
+        ends = np.cumsum([n + K for n in self.per_rank_rows])
+        self.table = np.concatenate([got[e - n - K:e - K] for e, n in zip(ends, self.per_rank_rows)], 0)
+        best = None
+        for e in ends:
+            k = got[e - K:e].reshape(-1)[:keys.size].reshape(keys.shape)
+            best = k if best is None else np.minimum(best, k)
+        if best is None:
+            best = keys
+        return [None if (best.shape[1] and best[m, 0] == big) or not best.shape[1] else best[m] % self.world == self.rank
+                for m in range(n_cand)]
 
 
 def sharded_metrics(p1, p2_local, r, p1_n=None, t1=None, device=None):

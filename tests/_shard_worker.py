@@ -98,6 +98,14 @@ def main():
     res['calls_two'] = list(calls)
     res['two'] = dict(data_list=dl, idx=[m['idx'] for m in md], metrics=[m['metrics'] for m in md],
                       has_points=['blocks_full' in m for m in md])
+    # 3b. the same cloud when the MIN keys are "too many" to ride in the all_gather: the three-collective path (all_reduce(MIN) kept)
+    os.environ['PCC_KEY_GATHER_MAX_BYTES'] = '0'
+    del calls[:]
+    dl3, md3, _ = model.compress_blocks(None, blocks_n, binstr_n, pn, 64, 2, with_normals=True, opt_metrics=['d1_mse', 'd2_mse'],
+                                        need_points=False)
+    del os.environ['PCC_KEY_GATHER_MAX_BYTES']
+    res['calls_two_big'] = list(calls)
+    res['two_big'] = dict(data_list=dl3, idx=[m['idx'] for m in md3], metrics=[m['metrics'] for m in md3])
     # 4. decompress_blocks: decoded points to rank 0
     CompressionModel._in_shard = False
     model.decompress_local = True

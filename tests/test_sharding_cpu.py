@@ -72,13 +72,18 @@ def test_two_rank_sharded_compress_equals_single_process(tmp_path):
                     assert np.isclose(ma[k], v, rtol=0.05), (k, ma[k], v)
     # the number of collectives DESIGN.md §6 states: no size exchanges (shard sizes are a function of (n_blocks, world))
     for r in range(2):
-        # round 5: the SUM of the candidates' partial tallies rides in the row all_gather: 3 collectives per cloud,
-        # whatever the number of candidates; the MIN over candidates x original points stays an all_reduce (8 B per point: an all_gather
-        # would move it `world` times)
-        assert two[r]['calls_compress'] == ['all_reduce', 'all_gather', 'gather', 'gather']   # last: --dec_files points
-        assert two[r]['calls_two'] == ['all_reduce', 'all_gather', 'gather']                 # 2 candidates, need_points=False
+        # round 5: TWO collectives per cloud, whatever the number of candidates (SURVEY.md 8e's "single gather" +
+        # the strings): the MIN keys ride in the row all_gather, the partial tallies with the strings; when the keys are too many to move
+        # `world` times (8 B per input point and candidate; bound PCC_KEY_GATHER_MAX_BYTES, default 64 MB) the MIN stays an all_reduce: three
+        assert two[r]['calls_compress'] == ['all_gather', 'all_gather', 'gather']             # last: --dec_files points
+        assert two[r]['calls_two'] == ['all_gather', 'all_gather']                           # 2 candidates, need_points=False
+        assert two[r]['calls_two_big'] == ['all_reduce', 'all_gather', 'gather']
+        assert two[r]['two_big']['idx'] == two[r]['two']['idx']
+        assert two[r]['two_big']['metrics'] == two[r]['two']['metrics']                        # same keys, same MIN, same tallies: same doubles
+    assert two[0]['two_big']['data_list'] == two[0]['two']['data_list'] and two[1]['two_big']['data_list'] is None
+    for r in range(2):
         assert two[r]['calls_dec'] == ['all_gather', 'gather']
-    assert one[0]['calls_compress'] == one[0]['calls_two'] == one[0]['calls_dec'] == []
+    assert one[0]['calls_compress'] == one[0]['calls_two'] == one[0]['calls_two_big'] == one[0]['calls_dec'] == []
     # decoder: all points on rank 0, in block order
     assert two[1]['dec'] is None and len(two[0]['dec']) == one[0]['n_blocks']
     for a, b in zip(two[0]['dec'], one[0]['dec']):
