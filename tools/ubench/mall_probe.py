@@ -29,3 +29,19 @@ print('input just written (whole tensor)        :', timed(lambda: x.copy_(y)))
 print('cache flushed by a 1 GB fill             :', timed(lambda: junk.zero_()))
 print('second half of the blocks written last   :', timed(lambda: (x[:16].copy_(y[:16]), x[16:].copy_(y[16:]))))
 print('nothing in between (back to back)        :', timed(lambda: None))
+
+
+# round 5: does the ORDER matter?  The consumer walks the blocks 0 .. 31 (workgroup index order).  If the producer wrote block 31 last, what
+# the 256 MB cache still holds (the last-written half) is read LAST, after the consumer's own traffic has pushed it out; if the producer
+# wrote block 0 last, the consumer starts on cached data.
+def write_order(order, step=4):
+    def prep():
+        for n0 in order:
+            x[n0:n0 + step].copy_(y[n0:n0 + step])
+    return prep
+
+
+print('written in blocks of 4, ascending  (0 .. 31) :', timed(write_order(range(0, 32, 4))))
+print('written in blocks of 4, descending (31 .. 0) :', timed(write_order(range(28, -1, -4))))
+print('written in blocks of 4, ascending  (0 .. 31) :', timed(write_order(range(0, 32, 4))))
+print('written in blocks of 4, descending (31 .. 0) :', timed(write_order(range(28, -1, -4))))
