@@ -96,6 +96,11 @@ struct SplitArgs {
     int flags, ocs, oco;
 };
 
+// (round 5) staging item -> (voxel, cin quad): the four voxels of 16 consecutive items are taken in the order 0, 2, 1, 3.  A ds_write_b128 is served
+// in groups of 8 lanes on 32 banks; two voxels 160 B apart overlap in 8 of them (2-way conflicts on every staging write: the 0.10 - 0.15 of
+// the PMC rows), 320 B apart they use the other 16 banks.  A bijection inside every aligned group of 16 items.
+__host__ __device__ constexpr int stage_perm(int item) { return (item & ~0xC) | ((item & 4) << 1) | ((item & 8) >> 1); }
+
 // TXW = 16: an MFMA row = 16 voxels of one y line.  TXW = 8 (the 8^3 grids of the 64-channel layers): a row = 2 y lines of 8 voxels.
 template <int CH, int TZ, int TY, int R, int CTW, int TXW = 16>
 struct SplitCfg {
@@ -157,7 +162,7 @@ conv_k3s1_split_kernel(SplitArgs a) {
     unsigned lw[C::LXP != C::LX ? C::ITEMS : 1];          // LDS dword offset of the item's voxel when the line pitch is padded
 #pragma unroll
     for (int it = 0; it < C::ITEMS; ++it) {
-        const int item = it * C::NT + tid;
+        const int item = stage_perm(it * C::NT + tid);
         const int u = item >> 2, q = item & 3;
         const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
         const int ly = rem / C::LX, lx = rem - ly * C::LX;
@@ -172,7 +177,7 @@ conv_k3s1_split_kernel(SplitArgs a) {
         for (int it = 0; it < C::ITEMS; it += 2) {
             u32x4 p1, p2, q1, q2;
             split_items2(p1, p2, q1, q2, stg[it], stg[it + 1]);
-            const int i0 = it * C::NT + tid, i1 = (it + 1) * C::NT + tid;
+            const int i0 = stage_perm(it * C::NT + tid), i1 = stage_perm((it + 1) * C::NT + tid);
             const unsigned o0 = C::LXP != C::LX ? lw[C::LXP != C::LX ? it : 0] : (unsigned)((i0 >> 2) * C::VS + (i0 & 3) * 4);
             const unsigned o1 = C::LXP != C::LX ? lw[C::LXP != C::LX ? it + 1 : 0] : (unsigned)((i1 >> 2) * C::VS + (i1 & 3) * 4);
             if (i0 < C::NV * 4) {
@@ -545,7 +550,7 @@ conv_tr2_split_kernel(SplitArgs a) {
     unsigned soff[C::ITEMS];
 #pragma unroll
     for (int it = 0; it < C::ITEMS; ++it) {
-        const int item = it * C::NT + tid;
+        const int item = stage_perm(it * C::NT + tid);
         const int u = item >> 2, q = item & 3;
         const int lz = u / (C::LY * C::LX), rem = u - lz * (C::LY * C::LX);
         const int ly = rem / C::LX, lx = rem - ly * C::LX;
@@ -558,7 +563,7 @@ conv_tr2_split_kernel(SplitArgs a) {
         for (int it = 0; it < C::ITEMS; it += 2) {
             u32x4 p1, p2, q1, q2;
             split_items2(p1, p2, q1, q2, stg[it], stg[it + 1]);
-            const int i0 = it * C::NT + tid, i1 = (it + 1) * C::NT + tid;
+            const int i0 = stage_perm(it * C::NT + tid), i1 = stage_perm((it + 1) * C::NT + tid);
             if (i0 < C::NV * 4) {
                 *reinterpret_cast<u32x4*>(lds + (i0 >> 2) * C::VS + (i0 & 3) * 4) = p1;
                 *reinterpret_cast<u32x4*>(lds + (i0 >> 2) * C::VS + 16 + (i0 & 3) * 4) = p2;

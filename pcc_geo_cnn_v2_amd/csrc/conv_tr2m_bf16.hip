@@ -148,16 +148,20 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
     }
     // ---- tile staging: global -> registers (one micro-step ahead) -> split -> LDS.  Item it of thread tid = (voxel u, channel quad q) =
     //      ((it * 256 + tid) >> 2, tid & 3); its operands go to u * 160 + q * 16 (B1) and + 64 (B2).  OOB items read zeros.
+    // (round 5) the four voxels of 16 consecutive lanes are taken in the order 0, 2, 1, 3: a ds_write_b128 is served in groups of 8 lanes on 32
+    // banks, and two voxels 160 B apart overlap in 8 of them (2-way conflicts on every staging write: the 0.10 - 0.18 of the PMC rows) -- 320 B apart
+    // they use the other 16 banks
+    const int gperm = ((tid >> 2) & ~3) | (((tid >> 2) & 1) << 1) | (((tid >> 2) >> 1) & 1);
     unsigned rel[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int item = it * NT + tid;
-        const int u = item >> 2, q = item & 3, ly = u / LXY, lx = u - ly * LXY;
+        const int u = it * 64 + gperm, q = item & 3, ly = u / LXY, lx = u - ly * LXY;
         const int y = Y0 - 1 + ly, x = X0 - 1 + lx;
         const bool ok = item < TILE_SLOTS && y >= 0 && y < a.H && x >= 0 && x < a.W;
         rel[it] = ok ? (unsigned)(((y * a.W + x) * CIN + q * 4) * 4) : kOOB;
     }
-    const unsigned cw = (unsigned)((tid >> 2) * VSB + (tid & 3) * 16);       // item it: cw + it * 64 * VSB
+    const unsigned cw = (unsigned)(gperm * VSB + (tid & 3) * 16);       // item it: cw + it * 64 * VSB
     f32x4 stg[ITEMS];
     // tile of (step sp, cin group cg): `addr` = address of channel 16 cg of input plane zb - 1 + sp (kept incrementally)
     auto fetch_tile = [&](int sp, int cg, unsigned long long addr) __attribute__((always_inline)) {

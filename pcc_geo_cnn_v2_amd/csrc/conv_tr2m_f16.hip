@@ -133,16 +133,19 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_f16_kernel(Args a, int nwg) {
     }
     // ---- tile staging: global -> registers (one micro-step ahead) -> fp16 -> LDS.  Item it of thread tid = (voxel u, quad q) =
     //      ((it * 256 + tid) >> 2, tid & 3): 8 channels = two 16-byte loads, one 16-byte LDS write at u * 96 + q * 16.  OOB items read zeros.
+    // the four voxels of 16 consecutive lanes are taken in the order 0, 2, 1, 3: a ds_write_b128 is served in groups of 8 lanes on 32 banks; two
+    // voxels 96 B apart overlap in 8 of them, 192 B apart they use the other 16 banks
+    const int gperm = ((tid >> 2) & ~3) | (((tid >> 2) & 1) << 1) | (((tid >> 2) >> 1) & 1);
     unsigned rel[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int item = it * NT + tid;
-        const int u = item >> 2, q = item & 3, ly = u / LXY, lx = u - ly * LXY;
+        const int u = it * 64 + gperm, q = item & 3, ly = u / LXY, lx = u - ly * LXY;
         const int y = Y0 - 1 + ly, x = X0 - 1 + lx;
         const bool ok = item < TILE_SLOTS && y >= 0 && y < a.H && x >= 0 && x < a.W;
         rel[it] = ok ? (unsigned)(((y * a.W + x) * CIN + q * 8) * 4) : kOOB;
     }
-    const unsigned cw = (unsigned)((tid >> 2) * VSB + (tid & 3) * 16);       // item it: cw + it * 64 * VSB (+ the tile buffer)
+    const unsigned cw = (unsigned)(gperm * VSB + (tid & 3) * 16);       // item it: cw + it * 64 * VSB (+ the tile buffer)
     f32x4 stg[ITEMS][2];
     // tile of (step sp, cin group cg): `addr` = address of channel 32 cg of input plane zb - 1 + sp (kept incrementally)
     auto fetch_tile = [&](int sp, int cg, unsigned long long addr) __attribute__((always_inline)) {
