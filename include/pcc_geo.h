@@ -56,7 +56,7 @@ int pcc_ctx_num_cu(pcc_ctx* ctx);
  * PCC_* variables named below) and changeable only through pcc_ctx_set_numerics -- never per call -- and it is recorded beside
  * every stream the CLIs write (gzip header comment, model_syntax.write_tagged_gzip) together with PCC_KERNEL_FAMILY, which is bumped whenever
  * a default kernel's summation order changes.  The decoder refuses a stream written under another tag. */
-#define PCC_KERNEL_FAMILY 5
+#define PCC_KERNEL_FAMILY 6
 #define PCC_NUM_NO_SPLIT 0x1         /* PCC_NO_SPLIT=1: every split-bf16 kernel off (exact-fp32 MFMA everywhere)              */
 #define PCC_NUM_NO_SPLIT_DIRECT 0x2  /* PCC_NO_SPLIT_DIRECT=1: the direct 32- / 64-channel split kernels off                  */
 #define PCC_NUM_NO_SPLIT_TR2 0x4     /* PCC_NO_SPLIT_TR2=1: the stride-2 transposed split kernels off                         */
@@ -71,7 +71,7 @@ int pcc_ctx_num_cu(pcc_ctx* ctx);
 #define PCC_NUM_SPLIT_MFMA32 0x800   /* PCC_SPLIT_MFMA=32: 32x32x16 formulation                                               */
 #define PCC_NUM_SPLIT_TILE8 0x1000   /* PCC_SPLIT_TILE=8                                                                      */
 #define PCC_NUM_P16 0x2000           /* PCC_P16=1: one 8-wave workgroup per CU in the direct 16 -> 16 kernel                  */
-#define PCC_NUM_NO_SPLIT32M 0x4000   /* PCC_NO_SPLIT32M=1: 32 -> 32 on grids > 16^3 stays on the exact-fp32 Winograd kernel  */
+#define PCC_NUM_NO_F16S 0x4000       /* PCC_NO_F16S=1: the Winograd layers keep three bf16 pieces / exact fp32 (no two-piece fp16 split) */
 #define PCC_NUM_COUT1_T16 0x8000     /* PCC_COUT1_T16=1: 16 x 16 columns in the 16 -> 1 last layer (same bits as 32 x 32: tested)  */
 /* family = PCC_KERNEL_FAMILY of this build, switches = OR of PCC_NUM_* in effect on this context */
 int pcc_ctx_get_numerics(pcc_ctx* ctx, uint32_t* family, uint32_t* switches);

@@ -33,7 +33,7 @@ ABI_VERSION = 4
 # include/pcc_geo.h "codec numerics": switches that select the kernel family of a layer (state of the context, recorded beside every stream)
 PCC_NUM = dict(no_split=0x1, no_split_direct=0x2, no_split_tr2=0x4, no_winograd=0x8, no_winograd32=0x10, no_winograd64=0x20,
                wino_per_group=0x40, no_tr2m=0x80, tr2m=0x100, tr2_old=0x200, split_mfma16=0x400, split_mfma32=0x800, split_tile8=0x1000,
-               p16=0x2000, no_split32m=0x4000, cout1_t16=0x8000)
+               p16=0x2000, no_f16s=0x4000, cout1_t16=0x8000)
 PCC_ERR_ARG, PCC_ERR_HIP, PCC_ERR_NOGPU, PCC_ERR_SPACE, PCC_ERR_CORRUPT = -1, -2, -3, -4, -5      # include/pcc_geo.h
 (PCC_NET_ANALYSIS_V1, PCC_NET_SYNTHESIS_V1, PCC_NET_ANALYSIS_V2, PCC_NET_SYNTHESIS_V2, PCC_NET_ANALYSIS_PROGRESSIVE_V2,
  PCC_NET_SYNTHESIS_PROGRESSIVE_V2, PCC_NET_HYPER_ANALYSIS, PCC_NET_HYPER_SYNTHESIS) = range(8)

@@ -20,7 +20,40 @@ struct pcc_ctx {
     // every dispatch decision that changes the bits of a layer tests this word, never getenv
     uint32_t numerics = 0;
     bool num(uint32_t bit) const { return (numerics & bit) != 0; }
+    // per-block max |x| slots of the fp16-split kernels for callers that chain layers themselves (pcc_conv3d; pcc_network_forward keeps
+    // its own in the workspace): grown on demand, one tensor per context like `scratch`
+    unsigned* amax = nullptr;
+    int amax_cap = 0;
 };
+int pcc_ctx_amax(pcc_ctx* ctx, int n, unsigned** ptr);
+// Side channel of the fp16-split kernels (conv_wino_f16s.hip): in_amax[n] = fp32 bits of max |in| over block n as recorded by the
+// layer that produced `in` (nullptr: the launcher computes it, pcc_block_amax); out_amax (zeroed by the caller, nullptr: not wanted)
+// receives the same for `out` from every kernel that can record it -- pcc_conv_records_amax says which.
+// A block's maximum is kept as PCC_AMAX_SLOTS partial maxima (row n = slots [n * PCC_AMAX_SLOTS, (n + 1) * PCC_AMAX_SLOTS)): thousands of
+// device-scope atomicMax on ONE address serialise (measured: 16 k of them on 32 addresses cost the first layer 100 us); a recording
+// wave picks its slot from its workgroup index, the reader takes the max over the 64 (one load per lane + a wave reduction).
+// out_recorded: set by the launcher when the kernel it chose fills out_amax
+constexpr int PCC_AMAX_SLOTS = 64;
+struct pcc_conv_ext { const unsigned* in_amax; unsigned* out_amax; bool out_recorded; };
+#ifdef __HIPCC__
+// lane-local running max -> slot `spread` of block row `row` (all lanes of the wave call it; inf is recorded as FLT_MAX, NaNs never arrive)
+__device__ __forceinline__ void pcc_amax_record(unsigned* row, float mx, int spread) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned mb = __builtin_bit_cast(unsigned, mx);
+        atomicMax(row + (spread & (PCC_AMAX_SLOTS - 1)), mb > 0x7f7fffffu ? 0x7f7fffffu : mb);
+    }
+}
+// max over the slots of a block row, wave-uniform (non-negative fp32 bit patterns order like unsigned integers)
+__device__ __forceinline__ unsigned pcc_amax_read(const unsigned* row) {
+    unsigned m = row[threadIdx.x & (PCC_AMAX_SLOTS - 1)];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off); m = o > m ? o : m; }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+}
+#endif
+int pcc_block_amax(pcc_ctx* ctx, const float* x, int N, size_t per_block, unsigned* amax, hipStream_t st);
 int pcc_ctx_scratch(pcc_ctx* ctx, size_t bytes, void** ptr);
 uint32_t pcc_numerics_from_env();
 void pcc_profile_free(pcc_ctx* ctx);
@@ -63,8 +96,12 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 // writes bit (z,y,x) of block n = (clip ? clamp01(x_hat) : x_hat) > thr[n] into `mask` (one bit per voxel, row-major, 32-bit
 // words little-endian).  *fused tells the caller whether the layer took that path (else: pcc_threshold_compact on x_hat).
 struct pcc_thr_fuse { const float* thr; int clip; uint32_t* mask; };
+struct pcc_conv_ext;
 int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
-                        const float* residual, float* out, const pcc_thr_fuse* fuse, bool* fused, hipStream_t st);
+                        const float* residual, float* out, const pcc_thr_fuse* fuse, bool* fused, pcc_conv_ext* ext, hipStream_t st);
+bool pcc_conv_wants_amax(const pcc_ctx* ctx, const pcc_conv_desc* d);
+int pcc_conv3d_ext(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w, const float* w_packed, const float* bias,
+                   const float* residual, float* out, pcc_conv_ext* ext, void* stream);
 // points from the bit mask (elementwise.hip): scratch = [B * D plane counts][B * D*H*W / 32 mask words]
 uint32_t* pcc_threshold_mask_of(int32_t* scratch, int32_t B, int32_t D);
 int pcc_threshold_from_mask(pcc_ctx* ctx, int32_t B, int32_t D, int32_t H, int32_t W, float* xyz, int32_t* counts, int64_t cap,
@@ -91,7 +128,7 @@ size_t pcc_tr2m_bf16_packed_floats(int Cin, int Cout);
 void pcc_tr2m_bf16_pack(int Cin, int Cout, const float* w_tr2g, float* out);
 bool pcc_tr2m_bf16_covers(const pcc_conv_desc* d);
 int pcc_conv_tr2m_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
-                       hipStream_t st);
+                       pcc_conv_ext* ext, hipStream_t st);
 // the march in the fp16 mode (conv_tr2m_f16.hip, round 5): fp32 input, fp16 MFMA, fp16 output (PCC_CONV_F16 | PCC_CONV_OUT16), 32 -> 16 and 64 -> 32
 bool pcc_tr2m_f16_covers(const pcc_conv_desc* d);
 int pcc_conv_tr2m_f16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_tr2g, const float* bias, void* out,
@@ -109,6 +146,13 @@ bool pcc_wino_bf16_covers(const pcc_conv_desc* d);      // (given pcc_wino_eligi
 void pcc_wino_bf16_pack(int ngroups, const float* u_f32, float* out);
 int pcc_conv_wino_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* ub_packed, const float* bias,
                        const float* residual, float* out, hipStream_t st);
+// two-piece fp16 Winograd path (conv_wino_f16s.hip, round 6): U as two fp16 pieces under one power-of-two scale per layer
+constexpr int PCC_WINO_UH_FLOATS = 48 * 2 * 64 * 4;
+constexpr int PCC_WINO_UH_TAIL = 64;                    // [0] = the scale
+bool pcc_wino_f16s_covers(const pcc_conv_desc* d);      // (given pcc_wino_eligible)
+void pcc_wino_f16s_pack(int ngroups, const float* u_f32, float* out);
+int pcc_conv_wino_f16s(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* uh_packed, const float* bias,
+                       const float* residual, float* out, pcc_conv_ext* ext, hipStream_t st);
 // direct k3 stride-1 convolution with split-bf16 operands for Cin = Cout in {32, 64} (conv_split.hip)
 size_t pcc_split_packed_floats(int C);
 void pcc_split_pack(int C, const float* wlog, float* out);

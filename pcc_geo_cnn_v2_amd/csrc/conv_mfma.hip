@@ -78,10 +78,12 @@ struct ConvArgs {
     const float* thr = nullptr;
     unsigned short* mask = nullptr;
     int thr_clip = 0;
+    // per-block max |out| for the fp16-split layer that consumes `out` (common.h, pcc_conv_ext); filled by conv_cin1_kernel
+    unsigned* amax_out = nullptr;
 };
 
-__device__ __forceinline__ void store_out(const ConvArgs& a, f32x4 v, size_t vox, int c0, int COUT) {
-    // v = 4 consecutive output channels c0..c0+3 of voxel `vox`
+__device__ __forceinline__ f32x4 store_out(const ConvArgs& a, f32x4 v, size_t vox, int c0, int COUT) {
+    // v = 4 consecutive output channels c0..c0+3 of voxel `vox`; returns what was stored (fp32 path)
     if (a.flags & PCC_CONV_BIAS) v += *reinterpret_cast<const f32x4*>(a.bias + c0);
     if (a.flags & PCC_CONV_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (a.flags & PCC_CONV_ADD) v += *reinterpret_cast<const f32x4*>(a.res + vox * COUT + c0);
@@ -96,6 +98,7 @@ __device__ __forceinline__ void store_out(const ConvArgs& a, f32x4 v, size_t vox
     } else {
         *reinterpret_cast<f32x4*>(a.out + vox * a.ocs + a.oco + c0) = v;
     }
+    return v;
 }
 
 // XCD-aware tile index: consecutive tile ids go to the same XCD (blocks are dispatched round-robin over
@@ -1135,15 +1138,21 @@ __global__ void __launch_bounds__((Cin1Cfg<COUT, KS, TZ, TY, R>::NT)) conv_cin1_
     }
 
     const int gz = oz0 + w_z;
+    float mx = 0.f;      // max |stored value| of this lane (NaNs skipped: fmaxf returns the other operand)
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int gy = oy0 + w_yg * R + i, gx = ox0 + v;
         if (gz < a.OD && gy < a.OH && gx < a.OW) {
             const size_t vox = (((size_t)n * a.OD + gz) * a.OH + gy) * a.OW + gx;
 #pragma unroll
-            for (int ct = 0; ct < C::NCT; ++ct) store_out(a, acc[i][ct], vox, ct * 16 + kq * 4, COUT);
+            for (int ct = 0; ct < C::NCT; ++ct) {
+                const f32x4 o = store_out(a, acc[i][ct], vox, ct * 16 + kq * 4, COUT);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            }
         }
     }
+    // the fp16-split layer behind this one scales block n by its max |x| (conv_wino_f16s.hip): order-independent atomicMax of bit patterns
+    if (a.amax_out != nullptr) pcc_amax_record(a.amax_out + (size_t)n * PCC_AMAX_SLOTS, mx, (int)blockIdx.x + wave);
 }
 
 // =====================================================================================================
@@ -1720,6 +1729,13 @@ PCC_API int pcc_conv_mfma_supported(const pcc_conv_desc* d) {
 // 64 -> 64 (conv_tr2_split_kernel, conv_split.hip)
 static bool tr2_has_split_image(int Cin, int Cout) { return (Cin == 32 && Cout == 16) || (Cin == 64 && (Cout == 32 || Cout == 64)); }
 
+// two-piece fp16 image of U behind everything else of a k3 stride-1 layer (conv_wino_f16s.hip): the 16- and 32-channel layers carry one
+static size_t wino_f16s_floats(int C) { return C <= 32 ? (size_t)NGROUPS(C) * NGROUPS(C) * PCC_WINO_UH_FLOATS + PCC_WINO_UH_TAIL : 0; }
+static size_t wino_f16s_offset(int C) {
+    return (size_t)27 * C * C + (size_t)NGROUPS(C) * NGROUPS(C) * (PCC_WINO_U_FLOATS + PCC_WINO_UB_FLOATS) + pcc_f16_packed_bytes(C) / 4 +
+           (C >= 32 ? pcc_split_packed_floats(C) : 0);
+}
+
 PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
     if (!d) return 0;
     const Plan p = make_plan(d);
@@ -1731,7 +1747,8 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
                 return k3 * d->Cin * d->Cout + (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_U_FLOATS +
                        pcc_f16_packed_bytes(d->Cin) / 4 +     // + the fp16 fragments of conv_f16.hip
                        (size_t)NGROUPS(d->Cin) * NGROUPS(d->Cout) * PCC_WINO_UB_FLOATS +    // + the split-bf16 image of U (conv_wino_bf16.hip)
-                       (d->Cin >= 32 ? pcc_split_packed_floats(d->Cin) : 0);                // + the split image of the direct kernel (conv_split.hip)
+                       (d->Cin >= 32 ? pcc_split_packed_floats(d->Cin) : 0) +              // + the split image of the direct kernel (conv_split.hip)
+                       wino_f16s_floats(d->Cin);                                            // + the two-piece fp16 image of U (conv_wino_f16s.hip)
             return k3 * d->Cin * d->Cout;
         case K_TR2:     // k3: second copy in the order of conv_tr2g_kernel; 32 -> 16: + its split-bf16 image (conv_tr2m_bf16.hip)
             return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1) + (d->k == 3 && tr2_has_split_image(d->Cin, d->Cout) ? pcc_tr2m_bf16_packed_floats(d->Cin, d->Cout) : 0);
@@ -1791,6 +1808,7 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                 float* ub = u + (size_t)NG * NCT * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(Cin) / 4;
                 pcc_wino_bf16_pack(NG, u, ub);
                 if (Cin >= 32) pcc_split_pack(Cin, wlog, ub + (size_t)NG * NCT * PCC_WINO_UB_FLOATS);
+                if (wino_f16s_floats(Cin)) pcc_wino_f16s_pack(NG, u, pk + wino_f16s_offset(Cin));
                 free(wlog);
             }
         }
@@ -1850,12 +1868,23 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
 
 int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
                     const float* residual, float* out, hipStream_t st) {
-    return pcc_conv3d_mfma_thr(ctx, d, in, w_packed, bias, residual, out, nullptr, nullptr, st);
+    return pcc_conv3d_mfma_thr(ctx, d, in, w_packed, bias, residual, out, nullptr, nullptr, nullptr, st);
+}
+
+// Does the kernel AUTO picks for this layer take the fp16-split path (it then wants the per-block max of its input)?
+bool pcc_conv_wants_amax(const pcc_ctx* ctx, const pcc_conv_desc* d) {
+    if (d->impl != PCC_IMPL_AUTO && d->impl != PCC_IMPL_WINOGRAD) return false;
+    if (d->flags & (PCC_CONV_F16 | PCC_CONV_IN16 | PCC_CONV_OUT16)) return false;
+    const Plan p = make_plan(d);
+    if (p.kind != K_FWD || !(pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && (p.flip ? 1 : d->stride) == 1)) return false;
+    if (ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_F16S | PCC_NUM_NO_WINOGRAD) || !pcc_wino_eligible(d)) return false;
+    return pcc_wino_f16s_covers(d);
 }
 
 int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
-                        const float* residual, float* out, const pcc_thr_fuse* fuse, bool* fused, hipStream_t st) {
+                        const float* residual, float* out, const pcc_thr_fuse* fuse, bool* fused, pcc_conv_ext* ext, hipStream_t st) {
     if (fused) *fused = false;
+    if (ext) ext->out_recorded = false;
     const Plan p = make_plan(d);
     PCC_REQUIRE(p.kind != K_NONE, "pcc_conv3d_mfma: shape not covered");
     ConvArgs a;
@@ -1898,6 +1927,9 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
             if (want && pcc_wino_eligible(d)) {
                 const float* u32 = w_packed + (size_t)27 * ci * co;
                 // split-bf16 operands on the bf16 MFMA pipe (fp32-equivalent, conv_wino_bf16.hip); PCC_NO_SPLIT=1: exact-fp32 MFMA (A/B)
+                // 16-channel layers: two fp16 pieces under a per-block power-of-two pre-scale (conv_wino_f16s.hip, round 6); PCC_NO_F16S=1: bf16 x 3
+                if (!ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_F16S) && pcc_wino_f16s_covers(d))
+                    return pcc_conv_wino_f16s(ctx, d, in, w_packed + wino_f16s_offset(ci), bias, residual, out, ext, st);
                 const bool split = !ctx->num(PCC_NUM_NO_SPLIT) && pcc_wino_bf16_covers(d);
                 if (split) return pcc_conv_wino_bf16(ctx, d, in, u32 + (size_t)(ci / 16) * (co / 16) * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(ci) / 4, bias, residual, out, st);
                 return pcc_conv_wino(ctx, d, in, u32, bias, residual, out, st);
@@ -1923,7 +1955,7 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
         if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {
             // 32 -> 16: split-bf16 operands on the bf16 MFMA pipe (conv_tr2m_bf16.hip); PCC_NO_SPLIT=1 / PCC_NO_SPLIT_TR2=1: exact fp32 (A/B)
             if (pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
-                return pcc_conv_tr2m_bf16(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, st);
+                return pcc_conv_tr2m_bf16(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, ext, st);
             return pcc_conv_tr2m(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
         }
         PCC_CASE_TR2(64, 64, 3) PCC_CASE_TR2(64, 32, 3) PCC_CASE_TR2(32, 16, 3) PCC_CASE_TR2(32, 32, 3)
@@ -1932,6 +1964,7 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
 #define PCC_CIN1(CO, K, TZ, TY, R)                                                                      \
     if (co == CO && k == K) {                                                                           \
         using C = Cin1Cfg<CO, K, TZ, TY, R>;                                                            \
+        if (ext && ext->out_amax && !(d->flags & PCC_CONV_OUT16)) { a.amax_out = ext->out_amax; ext->out_recorded = true; } \
         a.ntz = cdiv(a.OD, TZ); a.nty = cdiv(a.OH, TY); a.ntx = cdiv(a.OW, 16);                         \
         return launch(conv_cin1_kernel<CO, K, TZ, TY, R>, C::NT, C::LDS_BYTES, a.N * a.ntz * a.nty * a.ntx, a, st); \
     }

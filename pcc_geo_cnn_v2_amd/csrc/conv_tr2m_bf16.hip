@@ -93,6 +93,7 @@ struct Tr2mArgs {
     int N, D, H, W;      // input dims (output = 2x)
     int nty, ntx, zsplit, zlen, nct;
     int flags, ocs, oco;
+    unsigned* amax_out = nullptr;      // per-block max |out| for the fp16-split layer behind this one (common.h, pcc_conv_ext)
 };
 
 // tap t = 0..26 of a micro-step, kz-major; within a kz the (ky, kx) order keeps equal input offsets together and lets the
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
     int s = 0, c = 0;                                 // input plane step / cin group of the current micro-step
     unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(2 * (zb - 2)) * PLANE_O;   // planes 2 (z - 1), 2 (z - 1) + 1 of step s = 0
 
+    float mx = 0.f, mxt = 0.f;      // max |stored value|: all planes so far / the plane pair in flight (dropped with its stores when s < 2)
     // epilogue item e of a finished plane pair: e < 16: odd set (pz = 1), class e >> 2, row e & 3; else the old even_cur (pz = 0)
     auto finish = [&](auto ph_tag, auto e_tag, const __amdgpu_buffer_rsrc_t& rout, f32x4& keep) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value, e = decltype(e_tag)::value;
@@ -245,6 +247,8 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
         f32x4 o = acc_read(pz ? O[cls][i] : E[PH ^ 1][cls][i]);
         if (RELU) o = __builtin_elementwise_maximum(o, zero4);
         keep = o;
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mxt) : "v"(o[0]), "v"(o[1]));
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mxt) : "v"(o[2]), "v"(o[3]));
         const unsigned soff = (unsigned)pz * PLANE_O + (unsigned)(((2 * i + py) * OW + px) * a.ocs * 4);
         buf_store4(rout, keep, ob, soff);
     };
@@ -299,6 +303,7 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (FIRST && !HALO) { mx = fmaxf(mx, prev_ok ? mxt : 0.f); mxt = 0.f; }
         // the operand-form tile of the next micro-step is complete in LDS (this wave's ds_writes: lgkmcnt; the others': barrier)
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt / expcnt untouched (stores and the raw loads stay in flight)
         __syncthreads();
@@ -335,7 +340,10 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_bf16_kernel(Tr2mArgs a, int n
         }
 #pragma unroll
         for (int e = 0; e < 32; ++e) asm volatile("" ::"v"(keep[e]));
+        mx = fmaxf(mx, nsteps >= 2 ? mxt : 0.f);
     }
+    // ---- max |out| of block n for the fp16-split layer behind this one (conv_wino_f16s.hip): atomicMax of non-negative fp32 bit patterns
+    if (a.amax_out != nullptr) pcc_amax_record(a.amax_out + (size_t)n * PCC_AMAX_SLOTS, mx, (int)blockIdx.x * 4 + wave);
 }
 
 }  // namespace pcctr2mb
@@ -381,7 +389,7 @@ void pcc_tr2m_bf16_pack(int Cin, int Cout, const float* w_tr2g, float* out) {
 bool pcc_tr2m_bf16_covers(const pcc_conv_desc* d) { return pcc_tr2m_eligible(d) && d->Cin == 32 && d->Cout == 16; }
 
 int pcc_conv_tr2m_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
-                       hipStream_t st) {
+                       pcc_conv_ext* ext, hipStream_t st) {
     PCC_REQUIRE(pcc_tr2m_bf16_covers(d), "pcc_conv_tr2m_bf16: shape not covered");
     Tr2mArgs a;
     a.in = in; a.w = w_split; a.bias = bias; a.out = out;
@@ -390,6 +398,7 @@ int pcc_conv_tr2m_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
     a.flags = d->flags;
     a.ocs = d->out_cstride ? d->out_cstride : d->Cout;
     a.oco = d->out_coffset;
+    if (ext && ext->out_amax) { a.amax_out = ext->out_amax; ext->out_recorded = true; }
     const int base = d->N * (d->H / 16) * (d->W / 16) * (d->Cout / 16);
     int zs = 1;
     while (base * zs < ctx->num_cu && d->D % (zs * 2) == 0 && d->D / (zs * 2) >= 4) zs *= 2;

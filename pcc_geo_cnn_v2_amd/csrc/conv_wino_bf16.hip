@@ -37,10 +37,6 @@
 #ifndef PCC_WB_PROBE
 #define PCC_WB_PROBE 0
 #endif
-// -DPCC_WB_HALF_PROBE_BUILD=1 (tools/build_variant.sh): also builds conv16_wino_bf16_half_probe, the two-waves-per-SIMD timing probe of round 5
-#ifndef PCC_WB_HALF_PROBE_BUILD
-#define PCC_WB_HALF_PROBE_BUILD 0
-#endif
 
 namespace pccwino {
 
@@ -465,263 +461,6 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_bf16_kernel(WinoArgs a, int
 }
 
 
-#if PCC_WB_HALF_PROBE_BUILD
-// =====================================================================================================================================
-// PROBE (round 5): what would two waves per SIMD buy?  conv16_wino_bf16_half_probe is the kernel above cut down to
-// what ONE wave of a pair would execute if the 16 Winograd points were split between two waves by rows (py in {0, 1} here; its partner
-// would take {2, 3}): 8 waves per workgroup = two per SIMD, 96 accumulator registers, 64 piece registers, 6 slots of 12 MFMAs per step,
-// three of the four patch rows, one output row of the 2 x 2 tile per wave.  It leaves OUT what a real pair needs on top -- the exchange of
-// the x-reduced rows through LDS, its buffer (which does not fit beside the 96 KB U image and a 3-slot plane ring) and the second
-// barrier or double buffer that orders it -- and both halves run the SAME rows, so ITS RESULTS ARE WRONG BY CONSTRUCTION: it exists to
-// time an upper bound of the idea and to see what the register allocator makes of the budget (build with -DPCC_WB_HALF_PROBE_BUILD=1,
-// tools/bench_one.py with PCC_WB_HALF_PROBE=1; not part of the product library).
-// Outcome (profiles/r05_two_waves_probe.log): with the product's three K = 32 MFMAs per (tap, point) the wave needs 64 piece
-// registers and the allocator spills 114 VGPRs at 256 registers per wave (1190 us against 428).  Only the mixed-shape forms fit -- this one
-// (two K = 32 + two K = 16 MFMAs: 128 VGPRs + 128 AGPRs, no spill) and the one-K32-plus-four-K16 form of DESIGN.md section 8 (238
-// registers) -- and they are SLOWER than the product kernel although the exchange is not even paid: 460 - 469 us against 424 - 437 us alone,
-// GRBM cycles +10 % / +14 %, 26.0 M / 32.4 M MFMA instructions against 18.8 M, wait_inst 0.41 / 0.49 of the wave cycles against 0.21: the
-// second wave does not fill the first one's issue bubbles, it queues behind its MFMAs.
-// =====================================================================================================================================
-constexpr int NT2 = 512;
-constexpr int ITEMS_H = 3;          // chunks staged per wave: wave w8 stages chunks 3 w8 .. 3 w8 + 2 (21 chunks; the last three twice)
-
-template <bool RELU>
-__global__ void __launch_bounds__(NT2, 1) conv16_wino_bf16_half_probe(WinoArgs a, int nwg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & 3, half = wave8 >> 2;
-    const int t = lane & 15, g = lane >> 4;
-    auto ldsu = [&](unsigned off) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + off); };
-    auto ldsu2 = [&](unsigned off) -> u32x2 { return *reinterpret_cast<const u32x2*>(smem + off); };     // Ul = the first half of [Ul | Uh]
-    typedef const f32x4 __attribute__((address_space(3)))* lds_cf4;
-    auto lds_abs = [&](unsigned addr) -> f32x4 { return *(lds_cf4)(unsigned long long)addr; };
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-
-    int wg = xcd_remap(blockIdx.x, nwg);
-    const int tx_ = wg % a.ntx; wg /= a.ntx;
-    const int ty_ = wg % a.nty; wg /= a.nty;
-    const int zs = wg % a.zsplit;
-    const int n = wg / a.zsplit;
-    const int X0 = tx_ * 16, Y0 = ty_ * 16, zb = zs * a.zlen;
-    const int nsteps = a.zlen + 2;
-    const size_t HW = (size_t)a.H * a.W;
-    const unsigned HWI = (unsigned)(HW * a.ics * 4), HWR = (unsigned)(HW * a.rcs * 4), HWO = (unsigned)(HW * a.ocs * 4);
-    const float* in_n = a.in + (size_t)n * a.D * HW * a.ics + a.ico;
-    {
-        const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u, (unsigned)UB_BYTES);
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const int chunk = wave8 * 12 + k;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr)(smem + U_BASE + chunk * 1024), 16, (int)(lane * 16), chunk * 1024, 0, 0);
-        }
-    }
-    unsigned rel[ITEMS_H];
-    int chunk0 = wave8 * 3;
-    if (chunk0 > CHUNKS - 3) chunk0 = CHUNKS - 3;
-#pragma unroll
-    for (int it = 0; it < ITEMS_H; ++it) {
-        const int slot = (chunk0 + it) * 64 + lane;
-        const int R = slot / 146, rem = slot - R * 146;
-        const int v = 36 * R + (rem >> 2), c4 = rem & 3;
-        const int yrow = v / 18, r = v - yrow * 18, par = r >= 9 ? 1 : 0, col = r - 9 * par, xi = 2 * col + par;
-        const int y = Y0 - 1 + yrow, x = X0 - 1 + xi;
-        const bool ok = rem < 144 && v < PLANE_VOX && y >= 0 && y < a.H && x >= 0 && x < a.W;
-        rel[it] = ok ? (unsigned)(((y * a.W + x) * a.ics + c4 * 4) * 4) : kOOB;
-    }
-    auto stage_plane = [&](unsigned plane_off, int z) __attribute__((always_inline)) {
-        const bool ok = (unsigned)z < (unsigned)a.D;
-        const __amdgpu_buffer_rsrc_t rp = make_rsrc(in_n + (ok ? (size_t)z * HW * a.ics : 0), ok ? HWI : 0u);
-#pragma unroll
-        for (int it = 0; it < ITEMS_H; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + plane_off + (chunk0 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
-    };
-    unsigned long long in_pl = (unsigned long long)in_n + (unsigned long long)(long long)(zb + 1) * HWI;
-    const int wx = wave & 1, wy = wave >> 1;
-    const int TX = 4 * wx + (t & 3), TY = 4 * wy + (t >> 2);
-    const unsigned pa0 = (unsigned)(64 * (36 * TY + TX) + 16 * (g + 2 * TY));
-    auto pa_off = [](int dy, int dx) constexpr -> unsigned { return (unsigned)(64 * (18 * dy + 9 * (dx & 1) + (dx >> 1)) + (dy >= 2 ? 32 : 0)); };
-    const unsigned ua = (unsigned)(U_BASE + lane * 16);
-    const int ox0 = X0 + 2 * TX, oy0 = Y0 + 2 * TY + half;                // this wave finishes output row `half` of the 2 x 2 tile
-    const unsigned vox0 = (unsigned)(oy0 * a.W + ox0);
-    const unsigned ovo0 = (vox0 * (unsigned)a.ocs + (unsigned)a.oco + 4u * g) * 4u;
-    const unsigned rvo0 = (vox0 * (unsigned)a.rcs + 4u * g) * 4u;
-    const unsigned oso1 = (unsigned)a.ocs * 4u, rso1 = (unsigned)a.rcs * 4u;
-    const bool has_res = (a.flags & PCC_CONV_ADD) != 0;
-    const float* res_n = has_res ? a.res + (size_t)n * a.D * HW * a.rcs : a.in;
-    float* out_n = a.out + (size_t)n * a.D * HW * a.ocs;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 bias4 = (a.flags & PCC_CONV_BIAS) ? *reinterpret_cast<const f32x4*>(a.bias + g * 4) : zero4;
-
-    stage_plane(0u, zb - 1);
-    stage_plane((unsigned)PLANE_BYTES, zb);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-
-    u32x4 B1[8];                // [Vh | Vm] per point
-    u32x2 Bl[8];                // Vl: mixed MFMA shapes (one K = 32 + four K = 16 per (tap, point)) need no second copy of Vh
-    f32x4 P0[4], P1[4], P2[4];
-    float Y[16], Mr[16];
-    u32x4 A1[2];                // [Uh | Um] of the two points (px parity) in flight
-    u32x4 A2[2];                // [Ul | Uh]
-    f32x4 acc[3][8];
-    f32x4 S0, S1, resv[2], ost[2];
-    auto yrow = [&](auto r_tag) __attribute__((always_inline)) {
-        constexpr int r = decltype(r_tag)::value;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const f32x4 y = r == 0 ? sub4(P0[x], P2[x]) : add4(P1[x], P2[x]);
-            Y[4 * x + 0] = y[0]; Y[4 * x + 1] = y[1]; Y[4 * x + 2] = y[2]; Y[4 * x + 3] = y[3];
-        }
-    };
-    auto cvt_task = [&](auto r_tag, auto st_tag, auto j_tag) __attribute__((always_inline)) {
-        constexpr int r = decltype(r_tag)::value, st = decltype(st_tag)::value, j = decltype(j_tag)::value;
-        constexpr int x = j >> 1, hf = j & 1;
-        const unsigned v = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){Y[4 * x + 2 * hf], Y[4 * x + 2 * hf + 1]}, bf16x2));
-        if (st == 0) B1[r * 4 + x][hf] = v;
-        else if (st == 1) B1[r * 4 + x][2 + hf] = v;
-        else Bl[r * 4 + x][hf] = v;
-    };
-    auto dot_block = [&](auto r_tag, auto st_tag) __attribute__((always_inline)) {
-        constexpr int r = decltype(r_tag)::value, o = decltype(st_tag)::value == 0 ? 0 : 2;
-        dot2c_sub16(Y, B1[r * 4 + 0][o], B1[r * 4 + 0][o + 1], B1[r * 4 + 1][o], B1[r * 4 + 1][o + 1], B1[r * 4 + 2][o], B1[r * 4 + 2][o + 1],
-                    B1[r * 4 + 3][o], B1[r * 4 + 3][o + 1]);
-    };
-    auto load_prow = [&](f32x4 (&P)[4], int dy, unsigned slot_off) __attribute__((always_inline)) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) P[x] = *reinterpret_cast<const f32x4*>(smem + pa0 + pa_off(dy, x) + slot_off);
-    };
-    using R0 = std::integral_constant<int, 0>;
-    using R1 = std::integral_constant<int, 1>;
-    using ST0 = std::integral_constant<int, 0>;
-    using ST1 = std::integral_constant<int, 1>;
-    using ST2 = std::integral_constant<int, 2>;
-    auto split_row = [&](auto r_tag) __attribute__((always_inline)) {
-        yrow(r_tag);
-        static_for<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(r_tag, ST0{}, j); });
-        dot_block(r_tag, ST0{});
-        static_for<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(r_tag, ST1{}, j); });
-        dot_block(r_tag, ST1{});
-        static_for<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(r_tag, ST2{}, j); });
-    };
-    {
-        load_prow(P0, 0, 0u); load_prow(P1, 1, 0u); load_prow(P2, 2, 0u);
-        transform_x_row(P0); transform_x_row(P1); transform_x_row(P2);
-        split_row(R0{});
-        yrow(R1{});                                  // row 1 goes through the split in slots 0..2 of the first step
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }
-#pragma unroll
-    for (int px = 0; px < 2; ++px) { A1[px] = ldsu(ua + ub_row_off(0) + (unsigned)(px * UB_ROW_BYTES)); A2[px] = ldsu(ua + ub_row_off(0) + (unsigned)(px * UB_ROW_BYTES + 1024)); }
-    resv[0] = zero4; resv[1] = zero4; ost[0] = zero4; ost[1] = zero4; S0 = zero4; S1 = zero4;
-    unsigned rel_p[ITEMS_H];
-#pragma unroll
-    for (int i = 0; i < ITEMS_H; ++i) rel_p[i] = park(rel[i]);
-    const unsigned pa_p = park((unsigned)(unsigned long long)(lds_ptr)smem + pa0);
-    const unsigned ovo_p = park(ovo0), rvo_p = park(rvo0);
-    unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2) * HWR;
-    unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2) * HWO;
-
-    // One input plane, 6 slots q = (py = q / 3, dz = 2 - q % 3) of 12 MFMAs.  Input side, V row r in {0, 1} of plane s+1:
-    //   K(2) yrow(0); F(3) h, K(3) -h, F(4) m, K(4) -m, F(5) l;   K(5) yrow(1); F(0') h, K(0') -h, F(1') m, K(1') -m, F(2') l
-    //   patch rows: P2 F(0), P0 F(1), x-transforms K(1) / K(2);  P1 F(3), K(4);  plane s+2 -> LDS: F(3)
-    // Output side, row r of the finished plane: F(3r+2) AccVGPR reads, K(3r+2) A^T; K(5) epilogue of this wave's output row.
-    auto step = [&](auto ph_tag, int s) __attribute__((always_inline)) {
-        constexpr int PH = decltype(ph_tag)::value;
-        constexpr unsigned slotN = (unsigned)((PH + 1) % 3) * PLANE_BYTES;
-        constexpr unsigned slotW = (unsigned)((PH + 2) % 3) * PLANE_BYTES;
-        constexpr int AF = PH;
-        const bool zo_ok = s >= 2;
-        const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok ? HWO : 0u);
-        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res ? HWR : 0u);
-        res_pl += HWR; out_pl += HWO;
-        const bool in_ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc((const void*)(in_ok ? in_pl : (unsigned long long)in_n), in_ok ? HWI : 0u);
-        in_pl += HWI;
-        static_for<0, 6>([&](auto q_tag) __attribute__((always_inline)) {
-            constexpr int q = decltype(q_tag)::value;
-            constexpr int py = q / 3, dz = 2 - q % 3;
-            constexpr int as = (PH + 2 - dz) % 3;
-            constexpr int qn = (q + 1) % 6;
-            const unsigned un = ua + ub_row_off(qn);
-            constexpr bool opens = dz == 0;
-            using RS = std::integral_constant<int, (q / 3 + 1) % 2>;
-            using STG = std::integral_constant<int, q % 3>;
-            unsigned pa_s = 0, ovo_s = 0, rvo_s = 0;
-            if constexpr (q == 0 || q == 1 || q == 3) pa_s = unpark_lds(pa_p);
-            if constexpr (q == 5) ovo_s = unpark(ovo_p);
-            if constexpr (q == 0) rvo_s = unpark(rvo_p);
-            // 16 MFMAs: points px = 0..3 pairwise (two points alternate, a dependent MFMA is two issue slots away), four per point:
-            // K32 [Uh|Um].[Vh|Vm] (hh + mm), K32 [Ul|Uh].[Vh|Vm] (lh + hm), then K16 Uh.Vl, Um.Vh on aligned halves of the same registers
-            static_for<0, 16>([&](auto i_tag) __attribute__((always_inline)) {
-                constexpr int i = decltype(i_tag)::value;
-                {
-                    constexpr int h = i / 8, tm = (i % 8) / 2, px = 2 * h + (i & 1), pp = px & 1;
-                    constexpr int k = py * 4 + px;
-                    const f32x4 c = (opens && tm == 0) ? ((py == 1 && px == 1) ? bias4 : zero4) : acc[as][k];
-                    const u32x2 a_lo = __builtin_shufflevector(A1[pp], A1[pp], 0, 1), a_hi = __builtin_shufflevector(A1[pp], A1[pp], 2, 3);
-                    const u32x2 b_lo = __builtin_shufflevector(B1[k], B1[k], 0, 1);
-                    if constexpr (tm == 0) acc[as][k] = mfma_bf16(A1[pp], B1[k], c);
-                    else if constexpr (tm == 1) acc[as][k] = mfma_bf16(A2[pp], B1[k], c);
-                    else if constexpr (tm == 2) acc[as][k] = mfma_bf16_k16(a_lo, Bl[k], c);
-                    else acc[as][k] = mfma_bf16_k16(a_hi, b_lo, c);
-                    constexpr int nx = px + 2;                           // px + 2 of this row, or px - 2 of the next row
-                    if constexpr (tm == 1) A2[pp] = ldsu((nx < 4 ? ua + ub_row_off(q) + (unsigned)(nx * UB_ROW_BYTES) : un + (unsigned)((nx - 4) * UB_ROW_BYTES)) + 1024);
-                    if constexpr (tm == 3) A1[pp] = ldsu(nx < 4 ? ua + ub_row_off(q) + (unsigned)(nx * UB_ROW_BYTES) : un + (unsigned)((nx - 4) * UB_ROW_BYTES));
-                }
-                if constexpr (i < 8) cvt_task(RS{}, STG{}, i_tag);
-                if constexpr (q == 0 && i >= 8 && i < 12) P2[i - 8] = lds_abs(pa_s + pa_off(2, i - 8) + slotN);
-                if constexpr (q == 1 && i >= 8 && i < 12) P0[i - 8] = lds_abs(pa_s + pa_off(0, i - 8) + slotN);
-                if constexpr (q == 3 && i >= 8 && i < 12) P1[i - 8] = lds_abs(pa_s + pa_off(1, i - 8) + slotN);
-                if constexpr (q == 3 && i >= 12 && i < 15)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(smem + slotW + (chunk0 + i - 12) * 1024), 16, (int)unpark(rel_p[i - 12]), 0, 0, 0);
-                if constexpr (q % 3 == 2) {
-                    constexpr int r = q / 3;
-                    acc_read1(Mr[i], acc[AF][r * 4 + (i >> 2)][i & 3]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if constexpr (q % 3 == 0) dot_block(RS{}, ST0{});
-            if constexpr (q % 3 == 1) dot_block(RS{}, ST1{});
-            if constexpr (q == 1) transform_x_row(P2);
-            if constexpr (q == 2) { transform_x_row(P0); yrow(R0{}); }
-            if constexpr (q == 4) transform_x_row(P1);
-            if constexpr (q == 5) yrow(R1{});
-            if constexpr (q % 3 == 2) {
-                constexpr int r = q / 3;
-                const f32x4 m0 = {Mr[0], Mr[1], Mr[2], Mr[3]}, m1 = {Mr[4], Mr[5], Mr[6], Mr[7]}, m2 = {Mr[8], Mr[9], Mr[10], Mr[11]}, m3 = {Mr[12], Mr[13], Mr[14], Mr[15]};
-                const f32x4 r0 = add4(add4(m0, m1), m2), r1 = sub4(sub4(m1, m2), m3);
-                if (r == 0) { S0 = r0; S1 = r1; }
-                else { S0 = add4(S0, r0); S1 = add4(S1, r1); }
-            }
-            if constexpr (q == 5) {
-                f32x4 o0 = S0, o1 = S1;
-                if (RELU) { o0 = __builtin_elementwise_maximum(o0, zero4); o1 = __builtin_elementwise_maximum(o1, zero4); }
-                ost[0] = add4(o0, resv[0]); ost[1] = add4(o1, resv[1]);
-                buf_store4(rout, ost[0], ovo_s, 0u);
-                buf_store4(rout, ost[1], ovo_s, oso1);
-            }
-            if constexpr (q == 0) {
-                resv[0] = buf_load4(rres, rvo_s, 0u);
-                resv[1] = buf_load4(rres, rvo_s, rso1);
-            }
-            if constexpr (q == 0) { asm volatile("" ::"v"(ost[0])); asm volatile("" ::"v"(ost[1])); }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        __builtin_amdgcn_s_waitcnt(0x0F72);      // vmcnt(2): the three LDS-direct loads of F(3) have landed; younger: the two stores of K(5)
-        __syncthreads();
-    };
-    using P0t = std::integral_constant<int, 0>;
-    using P1t = std::integral_constant<int, 1>;
-    using P2t = std::integral_constant<int, 2>;
-    for (int s = 0; s < nsteps; s += 3) {
-        step(P0t{}, s);
-        if (s + 1 < nsteps) step(P1t{}, s + 1);
-        if (s + 2 < nsteps) step(P2t{}, s + 2);
-    }
-}
-
-#endif  // PCC_WB_HALF_PROBE_BUILD
 
 }  // namespace pccwino
 
@@ -787,15 +526,6 @@ int pcc_conv_wino_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
     static const kern_t kerns[4] = {conv16_wino_bf16_kernel<false, false>, conv16_wino_bf16_kernel<true, false>,
                                     conv16_wino_bf16_kernel<false, true>, conv16_wino_bf16_kernel<true, true>};
     const kern_t kern = kerns[((d->flags & PCC_CONV_RELU) ? 1 : 0) + ((d->flags & PCC_CONV_CLIP01) ? 2 : 0)];
-#if PCC_WB_HALF_PROBE_BUILD
-    if (getenv("PCC_WB_HALF_PROBE") != nullptr) {      // timing probe only (wrong results by construction, see conv16_wino_bf16_half_probe): tools/bench_one.py
-        const kern_t pk = conv16_wino_bf16_half_probe<true>;
-        { const int rc = pcc_enable_big_lds((const void*)pk, LDS_BYTES_B); if (rc != PCC_OK) return rc; }
-        hipLaunchKernelGGL(pk, dim3((unsigned)nwg), dim3(NT2), LDS_BYTES_B, st, a, nwg);
-        PCC_CHECK_HIP(hipGetLastError());
-        return PCC_OK;
-    }
-#endif
     { const int rc = pcc_enable_big_lds((const void*)kern, LDS_BYTES_B); if (rc != PCC_OK) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES_B, st, a, nwg);
     PCC_CHECK_HIP(hipGetLastError());

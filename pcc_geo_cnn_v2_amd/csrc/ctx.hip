@@ -53,7 +53,7 @@ uint32_t pcc_numerics_from_env() {
         {"PCC_NO_SPLIT", PCC_NUM_NO_SPLIT}, {"PCC_NO_SPLIT_DIRECT", PCC_NUM_NO_SPLIT_DIRECT}, {"PCC_NO_SPLIT_TR2", PCC_NUM_NO_SPLIT_TR2},
         {"PCC_NO_WINOGRAD", PCC_NUM_NO_WINOGRAD}, {"PCC_NO_WINOGRAD32", PCC_NUM_NO_WINOGRAD32}, {"PCC_NO_WINOGRAD64", PCC_NUM_NO_WINOGRAD64},
         {"PCC_WINO_PER_GROUP", PCC_NUM_WINO_PER_GROUP}, {"PCC_NO_TR2M", PCC_NUM_NO_TR2M}, {"PCC_TR2M", PCC_NUM_TR2M},
-        {"PCC_TR2_OLD", PCC_NUM_TR2_OLD}, {"PCC_NO_SPLIT32M", PCC_NUM_NO_SPLIT32M}, {"PCC_COUT1_T16", PCC_NUM_COUT1_T16}};
+        {"PCC_TR2_OLD", PCC_NUM_TR2_OLD}, {"PCC_NO_F16S", PCC_NUM_NO_F16S}, {"PCC_COUT1_T16", PCC_NUM_COUT1_T16}};
     uint32_t m = 0;
     for (const auto& f : flags)
         if (getenv(f.name) != nullptr) m |= f.bit;
@@ -88,9 +88,22 @@ int pcc_ctx_scratch(pcc_ctx* ctx, size_t bytes, void** ptr) {
     return PCC_OK;
 }
 
+int pcc_ctx_amax(pcc_ctx* ctx, int n, unsigned** ptr) {
+    if (n > ctx->amax_cap) {
+        if (ctx->amax) PCC_CHECK_HIP(hipFree(ctx->amax));
+        ctx->amax = nullptr; ctx->amax_cap = 0;
+        const int cap = n > 4096 ? n : 4096;
+        PCC_CHECK_HIP(hipMalloc((void**)&ctx->amax, (size_t)cap * sizeof(unsigned)));
+        ctx->amax_cap = cap;
+    }
+    *ptr = ctx->amax;
+    return PCC_OK;
+}
+
 PCC_API int pcc_ctx_destroy(pcc_ctx* ctx) {
     if (ctx) pcc_profile_free(ctx);
     if (ctx && ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx && ctx->amax) (void)hipFree(ctx->amax);
     delete ctx;
     return PCC_OK;
 }
@@ -114,6 +127,13 @@ PCC_API int pcc_conv_out_dims(const pcc_conv_desc* d, int32_t* OD, int32_t* OH, 
 PCC_API int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w,
                        const float* w_packed, const float* bias, const float* residual, float* out,
                        void* stream) {
+    return pcc_conv3d_ext(ctx, d, in, w, w_packed, bias, residual, out, nullptr, stream);
+}
+
+// pcc_conv3d with the side channel of the fp16-split kernels (common.h, pcc_conv_ext): what pcc_network_forward calls
+int pcc_conv3d_ext(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w, const float* w_packed, const float* bias,
+                   const float* residual, float* out, pcc_conv_ext* ext, void* stream) {
+    if (ext) ext->out_recorded = false;
     PCC_REQUIRE(ctx && d && in && out, "pcc_conv3d: NULL argument");
     PCC_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0,
                 "pcc_conv3d: non-positive dimension");
@@ -137,13 +157,13 @@ PCC_API int pcc_conv3d(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
     const bool fast_ok = w_packed != nullptr && pcc_conv_mfma_supported(d) == 1;
     if (d->flags & (PCC_CONV_IN16 | PCC_CONV_OUT16)) {
         PCC_REQUIRE(fast_ok && d->impl == PCC_IMPL_AUTO, "pcc_conv3d: fp16 storage needs the packed weights and PCC_IMPL_AUTO");
-        return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
+        return pcc_conv3d_mfma_thr(ctx, d, in, w_packed, bias, residual, out, nullptr, nullptr, ext, st);
     }
     if (d->impl == PCC_IMPL_MFMA || d->impl == PCC_IMPL_WINOGRAD || d->impl == PCC_IMPL_SPLIT) {
         PCC_REQUIRE(fast_ok, "pcc_conv3d: PCC_IMPL_MFMA/WINOGRAD/SPLIT requested but shape not covered or w_packed NULL");
-        return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
+        return pcc_conv3d_mfma_thr(ctx, d, in, w_packed, bias, residual, out, nullptr, nullptr, ext, st);
     }
-    if (d->impl == PCC_IMPL_AUTO && fast_ok) return pcc_conv3d_mfma(ctx, d, in, w_packed, bias, residual, out, st);
+    if (d->impl == PCC_IMPL_AUTO && fast_ok) return pcc_conv3d_mfma_thr(ctx, d, in, w_packed, bias, residual, out, nullptr, nullptr, ext, st);
     PCC_REQUIRE(w != nullptr, "pcc_conv3d: generic path needs the Keras-layout weights `w`");
     return pcc_conv3d_generic(ctx, d, in, w, bias, residual, out, st);
 }

@@ -122,6 +122,11 @@ size_t act_floats(const std::vector<LayerSpec>& v, int N, int D, int H, int W) {
     return align64(mx);
 }
 
+// behind the three activation buffers: one row of N per-block max |x| slots per layer output (the pre-scale side channel of the
+// fp16-split kernels, common.h pcc_conv_ext), zeroed by one memset per forward call
+inline size_t amax_row(int N) { return (size_t)N * PCC_AMAX_SLOTS; }       // uint32 slots per layer row
+inline size_t amax_bytes(size_t layers, int N) { return layers * amax_row(N) * sizeof(unsigned); }
+
 struct Profile {
     int transform = -1, layer = -1;
     int stride = 1;                 // every stride-th call of the selected layer is timed (the event records cost the queue ~6 us each)
@@ -216,7 +221,7 @@ PCC_API size_t pcc_network_workspace_bytes(int32_t transform, int32_t filters, i
     std::vector<LayerSpec> v;
     int c0;
     if (!build_layers(transform, filters, v, &c0) || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    return 3 * act_floats(v, N, D, H, W) * sizeof(float) + 256;
+    return 3 * act_floats(v, N, D, H, W) * sizeof(float) + 256 + amax_bytes(v.size(), N);
 }
 
 PCC_API int pcc_network_out_dims(int32_t transform, int32_t filters, int32_t D, int32_t H, int32_t W, int32_t* OD, int32_t* OH,
@@ -256,14 +261,16 @@ static int network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, con
                 "pcc_network_forward: layer_flags may hold PCC_CONV_F16, final_flags PCC_CONV_CLIP01");
     blob_layout(v, c0, im);
     const size_t af = act_floats(v, N, D, H, W);
-    PCC_REQUIRE(v.size() == 1 || (workspace && workspace_bytes >= 3 * af * sizeof(float)),
+    PCC_REQUIRE(v.size() == 1 || (workspace && workspace_bytes >= 3 * af * sizeof(float) + amax_bytes(v.size(), N)),
                 "pcc_network_forward: workspace too small (need pcc_network_workspace_bytes)");
     float* buf[3];
+    unsigned* amax = nullptr;      // [layer][amax_row(N)]
     {   // 256-byte aligned start
         uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
         for (int i = 0; i < 3; ++i) buf[i] = (float*)p + (size_t)i * af;
-        PCC_REQUIRE(v.size() == 1 || (uintptr_t)(buf[2] + af) <= (uintptr_t)workspace + workspace_bytes,
+        PCC_REQUIRE(v.size() == 1 || (uintptr_t)(buf[2] + af) + amax_bytes(v.size(), N) <= (uintptr_t)workspace + workspace_bytes,
                     "pcc_network_forward: workspace too small after alignment");
+        if (v.size() > 1) amax = (unsigned*)(buf[2] + af);
     }
     Profile* prof = ctx->profile ? (Profile*)ctx->profile : nullptr;
     hipStream_t st = (hipStream_t)stream;
@@ -276,6 +283,19 @@ static int network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, con
     // stride-1 convs run on conv_f16.hip (PCC_CONV_IN16), the last one adds the fp16 residual and writes fp32 for the next block.
     int f16_block_left = 0;      // layers of the current fp16-storage block still to come
     bool final_in16 = false;
+    // pre-scale side channel: does some layer take an fp16-split kernel at all (then the rows are zeroed once, here)?
+    bool amax_prev = false;      // the previous layer's kernel recorded the max |x| of its output blocks into its row
+    if (amax && !(layer_flags & PCC_CONV_F16)) {
+        bool any = false;
+        int aD = D, aH = H, aW = W;
+        for (size_t i = 0; i < v.size(); ++i) {
+            const pcc_conv_desc da = layer_desc(v[i], im[i].cin, N, aD, aH, aW, 0);
+            if (i > 0 && pcc_conv_wants_amax(ctx, &da)) any = true;
+            out_dims(v[i], aD, aH, aW);
+        }
+        if (any) { PCC_CHECK_HIP(hipSetDevice(ctx->device)); PCC_CHECK_HIP(hipMemsetAsync(amax, 0, amax_bytes(v.size(), N), (hipStream_t)stream)); }
+        else amax = nullptr;
+    } else amax = nullptr;
     for (size_t i = 0; i < v.size(); ++i) {
         const LayerSpec& L = v[i];
         const bool last = i + 1 == v.size();
@@ -331,15 +351,27 @@ static int network_forward(pcc_ctx* ctx, int32_t transform, int32_t filters, con
             PCC_CHECK_HIP(hipEventRecord(prof->ev[prof->used], st));
         }
         int rc;
+        // the layer's input maxima (if its producer recorded them) and where its own go (if the next layer will ask for them)
+        pcc_conv_ext ext = {nullptr, nullptr, false};
+        if (amax) {
+            if (i > 0 && amax_prev) ext.in_amax = amax + (i - 1) * amax_row(N);
+            if (!last) {
+                int nD = D, nH = H, nW = W;
+                out_dims(L, nD, nH, nW);
+                const pcc_conv_desc dn = layer_desc(v[i + 1], im[i + 1].cin, N, nD, nH, nW, 0);
+                if (pcc_conv_wants_amax(ctx, &dn)) ext.out_amax = amax + i * amax_row(N);
+            }
+        }
         if (last && fuse && im[i].pk_floats && d.impl == PCC_IMPL_AUTO && pcc_conv_mfma_supported(&d) == 1) {
             PCC_CHECK_HIP(hipSetDevice(ctx->device));
             rc = pcc_conv3d_mfma_thr(ctx, &d, in, blob + im[i].pk, L.bias ? blob + im[i].b : nullptr, L.res == 2 ? t1 : nullptr, out,
-                                     fuse, fused, st);
+                                     fuse, fused, &ext, st);
         } else {
-            rc = pcc_conv3d(ctx, &d, in, blob + im[i].w, im[i].pk_floats ? blob + im[i].pk : nullptr,
-                            L.bias ? blob + im[i].b : nullptr, L.res == 2 ? t1 : nullptr, out, stream);
+            rc = pcc_conv3d_ext(ctx, &d, in, blob + im[i].w, im[i].pk_floats ? blob + im[i].pk : nullptr,
+                                L.bias ? blob + im[i].b : nullptr, L.res == 2 ? t1 : nullptr, out, &ext, stream);
         }
         if (rc != PCC_OK) return rc;
+        amax_prev = ext.out_recorded;
         if (timed) { PCC_CHECK_HIP(hipEventRecord(prof->ev[prof->used + 1], st)); prof->used += 2; }
         out_dims(L, D, H, W);
         if (L.res == 1) { t1 = out; t1_buf = last ? -1 : cur; }

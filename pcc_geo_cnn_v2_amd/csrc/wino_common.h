@@ -52,6 +52,11 @@ struct WinoArgs {
     int ics, ico;       // input channel stride / offset of this launch's 16-channel cin group
     int rcs;            // residual channel stride (its channel offset follows the cout group)
     int ncig;           // cin groups processed by one launch of conv16_wino_cin_kernel (u: [cin group][cout group][48][64][4])
+    // fp16-split kernels (conv_wino_f16s.hip): per-block max |x| of the input (fp32 bit patterns, one per block n) that fixes the block's
+    // power-of-two pre-scale; where to record the same for the output (nullptr: not recorded); the weight image's scale (device, 1 float)
+    const unsigned* amax_in = nullptr;
+    unsigned* amax_out = nullptr;
+    const float* utail = nullptr;
 };
 
 // Measured on MI355X (tools/ubench/mfma_valu.hip): a wave's VALU instructions do NOT overlap with its own fp32 MFMAs
