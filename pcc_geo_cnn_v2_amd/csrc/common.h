@@ -147,7 +147,7 @@ void pcc_wino_bf16_pack(int ngroups, const float* u_f32, float* out);
 int pcc_conv_wino_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* ub_packed, const float* bias,
                        const float* residual, float* out, hipStream_t st);
 // two-piece fp16 Winograd path (conv_wino_f16s.hip, round 6): U as two fp16 pieces under one power-of-two scale per layer
-constexpr int PCC_WINO_UH_FLOATS = 48 * 2 * 64 * 4;
+constexpr int PCC_WINO_UH_FLOATS = 64 * 776 / 4;        // per (cin group, cout group): 64 lanes x (12 slots x 4 points x 16 B + 8 B pad)
 constexpr int PCC_WINO_UH_TAIL = 64;                    // [0] = the scale
 bool pcc_wino_f16s_covers(const pcc_conv_desc* d);      // (given pcc_wino_eligible)
 void pcc_wino_f16s_pack(int ngroups, const float* u_f32, float* out);
@@ -161,7 +161,7 @@ bool pcc_split_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d);
 // Conv3DTranspose k3 stride 2, 64 -> 32 / 64 -> 64, split operands (conv_split.hip); weights = pcc_tr2m_bf16_pack(tr2g-order image)
 bool pcc_tr2_split_covers(const pcc_conv_desc* d);
 int pcc_conv_tr2_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
-                       hipStream_t st);
+                       pcc_conv_ext* ext, hipStream_t st);
 int pcc_conv_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, const float* residual,
                    float* out, hipStream_t st);
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is set per DEVICE:

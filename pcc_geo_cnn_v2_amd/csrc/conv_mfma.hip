@@ -1871,14 +1871,29 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
     return pcc_conv3d_mfma_thr(ctx, d, in, w_packed, bias, residual, out, nullptr, nullptr, nullptr, st);
 }
 
-// Does the kernel AUTO picks for this layer take the fp16-split path (it then wants the per-block max of its input)?
+// The dispatch rules of the k3 stride-1 layers with Cin = Cout in {16, 32, 64} (shape + context state only), in the order
+// pcc_conv3d_mfma_thr applies them: 0 = a direct kernel, 1 = the direct split-bf16 kernel (conv_split.hip), 2 = Winograd exact fp32,
+// 3 = Winograd split-bf16 (16 channels), 4 = Winograd two-piece fp16 (16 / 32 channels, conv_wino_f16s.hip)
+static int k3s1_route(const pcc_ctx* ctx, const pcc_conv_desc* d) {
+    const int ci = d->Cin;
+    if (d->impl == PCC_IMPL_SPLIT) return 1;
+    if (d->impl == PCC_IMPL_AUTO && ci >= 32 && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_DIRECT) &&
+        pcc_split_covers(d) && pcc_split_preferred(ctx, d))
+        return 1;
+    const bool no_wino = ctx->num(PCC_NUM_NO_WINOGRAD), no_wino32 = ctx->num(PCC_NUM_NO_WINOGRAD32), wino64 = !ctx->num(PCC_NUM_NO_WINOGRAD64);
+    const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !(d->flags & PCC_CONV_F16) && !no_wino && !(ci == 32 && (no_wino32 || d->D < 16)) && !(ci == 64 && !wino64));
+    if (!(want && pcc_wino_eligible(d))) return 0;
+    if (!ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_F16S) && pcc_wino_f16s_covers(d) && (ci == 16 || !(d->flags & PCC_CONV_CLIP01))) return 4;
+    if (!ctx->num(PCC_NUM_NO_SPLIT) && pcc_wino_bf16_covers(d)) return 3;
+    return 2;
+}
+
+// Does the kernel picked for this layer take the fp16-split path (it then wants the per-block max of its input)?
 bool pcc_conv_wants_amax(const pcc_ctx* ctx, const pcc_conv_desc* d) {
-    if (d->impl != PCC_IMPL_AUTO && d->impl != PCC_IMPL_WINOGRAD) return false;
-    if (d->flags & (PCC_CONV_F16 | PCC_CONV_IN16 | PCC_CONV_OUT16)) return false;
+    if (d->flags & (PCC_CONV_IN16 | PCC_CONV_OUT16)) return false;
     const Plan p = make_plan(d);
     if (p.kind != K_FWD || !(pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && (p.flip ? 1 : d->stride) == 1)) return false;
-    if (ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_F16S | PCC_NUM_NO_WINOGRAD) || !pcc_wino_eligible(d)) return false;
-    return pcc_wino_f16s_covers(d);
+    return k3s1_route(ctx, d) == 4;
 }
 
 int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
@@ -1915,25 +1930,17 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
             // 32- / 64-channel layers: direct convolution on the bf16 MFMA pipe with split operands (conv_split.hip) where it beats the
             // fp32-MFMA Winograd kernel.  PCC_NO_SPLIT=1 (all split paths) / PCC_NO_SPLIT_DIRECT=1 (this one) for A/B runs
             const float* w_split = w_packed + (size_t)27 * ci * co + (size_t)(ci / 16) * (co / 16) * (PCC_WINO_U_FLOATS + PCC_WINO_UB_FLOATS) + pcc_f16_packed_bytes(ci) / 4;
-            if (d->impl == PCC_IMPL_SPLIT) {
+            const int route = k3s1_route(ctx, d);
+            if (route == 1) {
                 PCC_REQUIRE(ci >= 32 && pcc_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)), "pcc_conv3d: PCC_IMPL_SPLIT covers fp32 k3 stride-1 layers with Cin = Cout in {32, 64}, W % 16 == 0");
                 return pcc_conv_split(ctx, d, in, w_split, bias, residual, out, st);
             }
-            if (d->impl == PCC_IMPL_AUTO && ci >= 32 && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_DIRECT) &&
-                pcc_split_covers(d) && pcc_split_preferred(ctx, d))
-                return pcc_conv_split(ctx, d, in, w_split, bias, residual, out, st);
-            const bool no_wino = ctx->num(PCC_NUM_NO_WINOGRAD), no_wino32 = ctx->num(PCC_NUM_NO_WINOGRAD32), wino64 = !ctx->num(PCC_NUM_NO_WINOGRAD64);
-            const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !(d->flags & PCC_CONV_F16) && !no_wino && !(ci == 32 && (no_wino32 || d->D < 16)) && !(ci == 64 && !wino64));
-            if (want && pcc_wino_eligible(d)) {
-                const float* u32 = w_packed + (size_t)27 * ci * co;
-                // split-bf16 operands on the bf16 MFMA pipe (fp32-equivalent, conv_wino_bf16.hip); PCC_NO_SPLIT=1: exact-fp32 MFMA (A/B)
-                // 16-channel layers: two fp16 pieces under a per-block power-of-two pre-scale (conv_wino_f16s.hip, round 6); PCC_NO_F16S=1: bf16 x 3
-                if (!ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_F16S) && pcc_wino_f16s_covers(d))
-                    return pcc_conv_wino_f16s(ctx, d, in, w_packed + wino_f16s_offset(ci), bias, residual, out, ext, st);
-                const bool split = !ctx->num(PCC_NUM_NO_SPLIT) && pcc_wino_bf16_covers(d);
-                if (split) return pcc_conv_wino_bf16(ctx, d, in, u32 + (size_t)(ci / 16) * (co / 16) * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(ci) / 4, bias, residual, out, st);
-                return pcc_conv_wino(ctx, d, in, u32, bias, residual, out, st);
-            }
+            const float* u32 = w_packed + (size_t)27 * ci * co;
+            // two fp16 pieces under a per-block power-of-two pre-scale (conv_wino_f16s.hip, round 6: 16- and 32-channel layers);
+            // PCC_NO_F16S=1: three bf16 pieces (16 channels) / exact fp32; PCC_NO_SPLIT=1: exact-fp32 MFMA everywhere (A/B)
+            if (route == 4) return pcc_conv_wino_f16s(ctx, d, in, w_packed + wino_f16s_offset(ci), bias, residual, out, ext, st);
+            if (route == 3) return pcc_conv_wino_bf16(ctx, d, in, u32 + (size_t)(ci / 16) * (co / 16) * PCC_WINO_U_FLOATS + pcc_f16_packed_bytes(ci) / 4, bias, residual, out, st);
+            if (route == 2) return pcc_conv_wino(ctx, d, in, u32, bias, residual, out, st);
             PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD needs W and H multiples of 16");
         } else {
             PCC_REQUIRE(d->impl != PCC_IMPL_WINOGRAD, "pcc_conv3d: PCC_IMPL_WINOGRAD covers Cin = Cout in {16,32,64} k3 stride-1 layers only");
@@ -1949,7 +1956,7 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
         // PCC_NO_SPLIT_TR2=1: the exact-fp32 kernels below (A/B)
         if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) &&
             !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
-            return pcc_conv_tr2_split(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, st);
+            return pcc_conv_tr2_split(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, ext, st);
         // z-marching kernel (conv_tr2m.hip) for the 32 -> 16 / 64 -> 32 layers on grids of 16-multiples.  PCC_NO_TR2M=1 keeps the
         // tiled conv_tr2g_kernel, PCC_TR2M=1 takes the marching kernel wherever it is eligible (A/B runs, tests)
         if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {

@@ -94,6 +94,7 @@ struct SplitArgs {
     int N, D, H, W;
     int ntz, nty, ntx;
     int flags, ocs, oco;
+    unsigned* amax_out = nullptr;      // per-block max |out| for the fp16-split layer behind this one (common.h, pcc_conv_ext); conv_tr2_split_kernel
 };
 
 // (round 5) staging item -> (voxel, cin quad): the four voxels of 16 consecutive items are taken in the order 0, 2, 1, 3.  A ds_write_b128 is served
@@ -615,6 +616,7 @@ conv_tr2_split_kernel(SplitArgs a) {
     }
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + (size_t)n * ovox_n * a.ocs, (unsigned)(ovox_n * a.ocs * 4u));
     const float relu_lo = (a.flags & PCC_CONV_RELU) ? 0.f : -__builtin_inff();
+    float mx = 0.f;      // max |stored value| of this lane (amax_out)
 
     auto group = [&](auto last_tag, int g) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
@@ -667,6 +669,9 @@ conv_tr2_split_kernel(SplitArgs a) {
                         f32x4 o = acc[cls][i][ct];
                         o = __builtin_elementwise_maximum(o, (f32x4){relu_lo, relu_lo, relu_lo, relu_lo});
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, (int)(ooff[i] + coff + (unsigned)((ct0 + ct) * 16) * 4u), 0, 0);
+                        // rows beyond the volume (their stores are dropped by the range check) stay out of the block's maximum
+                        const float m4 = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                        mx = ooff[i] < kOOB ? fmaxf(mx, m4) : mx;
                     }
             }
         });
@@ -679,6 +684,8 @@ conv_tr2_split_kernel(SplitArgs a) {
         __syncthreads();
     }
     group(std::true_type{}, C::NG - 1);
+    // ---- max |out| of block n for the fp16-split layer behind this one (conv_wino_f16s.hip)
+    if (a.amax_out != nullptr) pcc_amax_record(a.amax_out + (size_t)n * PCC_AMAX_SLOTS, mx, (int)blockIdx.x * (C::NT / 64) + wave);
 }
 
 }  // namespace pccsplit
@@ -754,13 +761,14 @@ bool pcc_tr2_split_covers(const pcc_conv_desc* d) {
 }
 
 int pcc_conv_tr2_split(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
-                       hipStream_t st) {
+                       pcc_conv_ext* ext, hipStream_t st) {
     (void)ctx;
     PCC_REQUIRE(pcc_tr2_split_covers(d), "pcc_conv_tr2_split: shape not covered");
     SplitArgs a;
     a.in = in; a.w = w_split; a.bias = bias; a.res = nullptr; a.out = out;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
     a.flags = d->flags; a.ocs = d->out_cstride ? d->out_cstride : d->Cout; a.oco = d->out_coffset;
+    if (ext && ext->out_amax) { a.amax_out = ext->out_amax; ext->out_recorded = true; }
 #define PCC_TR2S_LAUNCH(CO, TZ, TY, R, CTW, TXW)                                                                  \
     {                                                                                                              \
         using C = Tr2SplitCfg<64, CO, TZ, TY, R, CTW, TXW>;                                                        \

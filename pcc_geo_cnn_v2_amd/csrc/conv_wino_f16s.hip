@@ -38,7 +38,7 @@
 #ifndef PCC_WH_PROBE
 #define PCC_WH_PROBE 0
 #endif
-// where the 16 v_fma_mix ops of a V row go: 0 = two per MFMA gap of slot 3r + 4, 1 = one block behind that slot's MFMAs
+// where the 16 v_fma_mix ops of a V row go: 0 = two per MFMA gap of slot 3r + 4, 1 = one block behind that slot's MFMAs (all-asm LDS form: 0 is 3 % faster, wait_lds 0.038 vs 0.086 of the wave cycles)
 #ifndef PCC_WH_MIXK
 #define PCC_WH_MIXK 0
 #endif
@@ -48,9 +48,14 @@ namespace pccwino {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int UH_ROW_BYTES = 2048;                       // per (dz, point): A1 = [Uh | Uh] (64 lanes x 16 B), A2 = [Ul | Ul]
-constexpr int UH_BYTES = 48 * UH_ROW_BYTES;              // 98304
-constexpr int LDS_BYTES_H = U_BASE + UH_BYTES;           // 162816 <= 160 KB
+// U in LDS, lane-contiguous: lane L of (cin group, cout group) owns 776 B = [slot q = 3 py + 2 - dz][px][4 h | 4 l fp16] (768 B) + 8 B
+// pad.  One ds_read2_b64 with offset0 == offset1 delivers the 8 bytes of a piece TWICE into four consecutive registers: the
+// duplicated MFMA operands [Uh | Uh] / [Ul | Ul] without a duplicated image (48.5 KB per group pair instead of 96 KB: two cin groups
+// fit beside the tile ring).  Every offset fits the 8-bit x 8 B field of that instruction, so a lane needs ONE address per cin group;
+// 776 = 3 x 256 + 8 spreads 32 lanes over all 64 banks (no conflicts).
+constexpr int UL_LANE_BYTES = 776;
+constexpr int UG_BYTES = 64 * UL_LANE_BYTES;             // 49664 per (cin group, cout group)
+__host__ __device__ constexpr int f16s_lds_bytes(int G) { return U_BASE + ((G * UG_BYTES + 1023) / 1024) * 1024; }      // 114688 / 163840 (= 160 KB)
 
 __device__ __forceinline__ f32x4 mfma_f16(const u32x4& a, const u32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -64,6 +69,35 @@ __device__ __forceinline__ unsigned mix_low_pair(unsigned H, float a, float b) {
     asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
                  "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(L) : "v"(H), "v"(a), "v"(b));
     return L;
+}
+// ---- LDS reads as inline asm.  The compiler does not know these are LDS operations: it inserts no s_waitcnt for them -- in
+// particular not the lgkmcnt(0) it puts in front of every s_barrier while reads it knows about are in flight (the U prefetch of the
+// next step's first row used to be drained there, once per step) -- and the kernel waits by count: LDS reads return in order, ALL
+// LDS reads of the march are issued here, at fixed places of the compile-time schedule, so "at most N younger reads outstanding"
+// is a constant per place.  The wait carries the registers it covers as in-out operands: nothing that uses them can be moved above it.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read2_dup(unsigned addr) {      // {8 bytes at addr + OFF} twice
+    u32x4 v;
+#if PCC_WH_PROBE & 2048      // timing only: one 16-byte read at the same place (wrong operands)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF & ~15));
+#else
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%2" : "=v"(v) : "v"(addr), "n"(OFF / 8));
+#endif
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read128(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_u(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"((PCC_WH_PROBE & 4096) ? 15 : N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_p(f32x4 (&P)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]) : "n"(N));
 }
 __device__ __forceinline__ void acc_read1h(float& d, const float& a) { asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d) : "a"(a)); }
 
@@ -130,7 +164,6 @@ __host__ __device__ constexpr int mh_first_slot(int mode) {
         if (mh_row_active(mode, 2 - n % 3)) return n;
     return 0;
 }
-__host__ __device__ constexpr unsigned uh_row_off(int q) { return (unsigned)(q * 4 * UH_ROW_BYTES); }       // the image is stored in slot order: row (py, dz) of slot q, px = 0
 
 // The block's pre-scale from its recorded max |x| (fp32 bits m, finite): biased exponent of s = 127 + 12 - (e - 127), kept inside
 // [1, 254] and such that s su stays inside 2^+-120 (su = the weight image's scale, exponent lsu).  m = 0: s = 1.
@@ -142,14 +175,19 @@ __device__ __forceinline__ unsigned f16s_scale_bits(unsigned m, int lsu) {
     return (unsigned)se << 23;
 }
 
-template <bool RELU, bool CLIP>
+// G = Cin / 16 = Cout / 16 in {1, 2}.  The march is a sequence of MICRO-STEPS m = (input plane s, cin group c), c fastest (G = 1: one per
+// plane): micro-step m multiplies the pieces of tile m (registers B) with U[c]; meanwhile tile m + 1 is read from the LDS ring,
+// transformed and split into the same registers behind their last use, and tile m + 2 arrives global -> LDS.  The three output planes
+// in flight (192 AccVGPRs, ONE cout group per workgroup) stay live across the cin groups; only the last group of a plane reduces and
+// stores the finished output plane.  Ring slot of tile m = m mod 3 = (G (s mod 3) + c) mod 3: compile time, like the accumulator phase.
+template <bool RELU, bool CLIP, int G>
 __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int nwg) {
+    static_assert(G == 1 || G == 2, "one or two 16-channel cin groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = lane & 15, g = lane >> 4;
-    auto ldsr = [&](unsigned off) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + off); };
-    auto ldsu = [&](unsigned off) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + off); };
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr)smem;       // absolute LDS address of the dynamic segment
 
     int wg = xcd_remap(blockIdx.x, nwg);
     const int cog = wg % a.nco; wg /= a.nco;
@@ -163,13 +201,15 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
     const unsigned HWI = (unsigned)(HW * a.ics * 4), HWR = (unsigned)(HW * a.rcs * 4), HWO = (unsigned)(HW * a.ocs * 4);
     const float* in_n = a.in + (size_t)n * a.D * HW * a.ics + a.ico;
 
-    // ---- U -> LDS: 96 KB straight global -> LDS (24 pieces of 1 KB per wave)
+    // ---- U -> LDS: the G images of this cout group ([cout group][cin group][lane][776 B], contiguous) straight global -> LDS
     {
-        const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u + (size_t)cog * (UH_BYTES / 4), (unsigned)UH_BYTES);
+        constexpr int UBYTES = G * UG_BYTES, NCH = (UBYTES + 1023) / 1024;
+        const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u + (size_t)cog * (UBYTES / 4), (unsigned)UBYTES);      // beyond the image: zeros
 #pragma unroll
-        for (int k = 0; k < 24; ++k) {
-            const int chunk = wave * 24 + k;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr)(smem + U_BASE + chunk * 1024), 16, (int)(lane * 16), chunk * 1024, 0, 0);
+        for (int k = 0; k < (NCH + 3) / 4; ++k) {
+            const int chunk = k * 4 + wave;
+            if (chunk < NCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr)(smem + U_BASE + chunk * 1024), 16, (int)(lane * 16), chunk * 1024, 0, 0);
         }
     }
     // ---- scales (wave-uniform): su of the weight image, s of this block, their product for the bias, its inverse for the epilogue
@@ -179,7 +219,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
     const float sprod = su * sv, sinv = 1.0f / sprod;          // powers of two inside 2^+-120: exact
     const f32x2 s2 = {sv, sv}, inv2 = {sinv, sinv};
 
-    // ---- plane staging (layout and addressing: conv_wino_bf16.hip)
+    // ---- tile staging (layout and addressing: conv_wino_bf16.hip)
     unsigned rel[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -191,21 +231,24 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
         const bool ok = rem < 144 && v < PLANE_VOX && y >= 0 && y < a.H && x >= 0 && x < a.W;
         rel[it] = ok ? (unsigned)(((y * a.W + x) * a.ics + c4 * 4) * 4) : kOOB;
     }
-    auto stage_plane = [&](unsigned plane_off, int z) __attribute__((always_inline)) {
+    // tile (input plane index sp of this slab, cin group cg) -> ring slot `ring_off`
+    auto stage_tile = [&](unsigned ring_off, int sp, int cg) __attribute__((always_inline)) {
+        const int z = zb - 1 + sp;
         const bool ok = (unsigned)z < (unsigned)a.D;
-        const __amdgpu_buffer_rsrc_t rp = make_rsrc(in_n + (ok ? (size_t)z * HW * a.ics : 0), ok ? HWI : 0u);
+        const __amdgpu_buffer_rsrc_t rp = make_rsrc(in_n + (ok ? (size_t)z * HW * a.ics + 16 * cg : 0), ok ? HWI - (unsigned)(64 * cg) : 0u);
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + plane_off + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr)(smem + ring_off + (wave * 5 + it) * 1024), 16, (int)rel[it], 0, 0, 0);
     };
-    unsigned long long in_pl = (unsigned long long)in_n + (unsigned long long)(long long)(zb + 1) * HWI;   // plane s+2 of step s = 0
 
-    // ---- per-lane patch read addresses (ring slot 0), tile of this lane
+    // ---- per-lane LDS addresses (absolute): patch (dy, dx) = (0, 0) of this lane's tile in ring slot 0; this lane's U rows per cin group
     const int wx = wave & 1, wy = wave >> 1;
     const int TX = 4 * wx + (t & 3), TY = 4 * wy + (t >> 2);
-    const unsigned pa0 = (unsigned)(64 * (36 * TY + TX) + 16 * (g + 2 * TY));       // patch (dy, dx) = (0, 0) of this lane in ring slot 0
-    auto pa_off = [](int dy, int dx) constexpr -> unsigned { return (unsigned)(64 * (18 * dy + 9 * (dx & 1) + (dx >> 1)) + (dy >= 2 ? 32 : 0)); };
-    const unsigned ua = (unsigned)(U_BASE + lane * 16);
+    const unsigned pa0 = lds0 + (unsigned)(64 * (36 * TY + TX) + 16 * (g + 2 * TY));
+    constexpr auto pa_off = [](int dy, int dx) constexpr -> int { return 64 * (18 * dy + 9 * (dx & 1) + (dx >> 1)) + (dy >= 2 ? 32 : 0); };
+    unsigned ua[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) ua[c] = lds0 + (unsigned)(U_BASE + c * UG_BYTES + lane * UL_LANE_BYTES);
 
     // ---- epilogue addressing: lane writes couts 4g..4g+3 of the 2x2 voxels of its tile
     const int ox0 = X0 + 2 * TX, oy0 = Y0 + 2 * TY;
@@ -229,13 +272,14 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
     // head / tail planes as in conv16_wino_kernel (wave-uniform, decided outside the MFMA stream)
     const bool first_zero = zb == 0, last_zero = zb + a.zlen == a.D;
     const int s0 = first_zero ? 1 : 0;
-    stage_plane((unsigned)s0 * PLANE_BYTES, zb - 1 + s0);
-    stage_plane((unsigned)(s0 + 1) * PLANE_BYTES, zb + s0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): U and both planes have landed
+    // tiles m0 = G s0 and m0 + 1 -> their ring slots
+    stage_tile((unsigned)((G * s0) % 3) * PLANE_BYTES, s0, 0);
+    stage_tile((unsigned)((G * s0 + 1) % 3) * PLANE_BYTES, G == 1 ? s0 + 1 : s0, G == 1 ? 0 : 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): U and both tiles have landed
     __syncthreads();
 
-    u32x4 B[16];                // pieces of s B^T d B of the current input plane: [Vh | Vl]
-    f32x4 P0[4], P1[4], P2[4], P3[4];      // x-transformed (and scaled) patch rows of the NEXT plane
+    u32x4 B[16];                // pieces of s B^T d B of the current tile: [Vh | Vl]
+    f32x4 P0[4], P1[4], P2[4], P3[4];      // x-transformed (and scaled) patch rows of the NEXT tile
     float Y[16];                // fp32 row of V on its way through the split: (point x, channel c) at 4x + c
     float Mr[16];               // accumulators of the finished plane's row on their way through A^T
     u32x4 A1[4], A2[4];         // U fragments of the row in flight: [Uh | Uh], [Ul | Ul] per point px
@@ -243,7 +287,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
     f32x4 S[2][2];
     f32x4 resv[4], ost[4];
     float mx = 0.f;             // max |stored value| of this lane (amax_out)
-    // ---- pieces of the schedule.  V row r of a plane: Y = its fp32 values (yrow), H = cvt(Y), Y -= H, L = cvt(Y).
+    // ---- pieces of the schedule.  V row r of a tile: Y = its fp32 values (yrow), H = cvt_pk(Y), L = fma_mix(Y - H).
     auto yrow = [&](auto r_tag) __attribute__((always_inline)) {
         constexpr int r = decltype(r_tag)::value;
 #pragma unroll
@@ -261,10 +305,6 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
         else if constexpr (st == 1)
             B[r * 4 + x][2 + hf] = mix_low_pair(B[r * 4 + x][hf], Y[4 * x + 2 * hf], Y[4 * x + 2 * hf + 1]);
     };
-    auto load_prow = [&](f32x4 (&P)[4], int dy, unsigned slot_off) __attribute__((always_inline)) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) P[x] = ldsr(pa0 + pa_off(dy, x) + slot_off);
-    };
     using R0 = std::integral_constant<int, 0>;
     using R1 = std::integral_constant<int, 1>;
     using R2 = std::integral_constant<int, 2>;
@@ -277,63 +317,84 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
         static_for_h<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(r_tag, ST0{}, j); });
         static_for_h<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(r_tag, ST1{}, j); });
     };
-    {
-        const unsigned so = (unsigned)s0 * PLANE_BYTES;
-        load_prow(P0, 0, so); load_prow(P1, 1, so); load_prow(P2, 2, so); load_prow(P3, 3, so);
-        transform_x_row_s(P0, s2); transform_x_row_s(P1, s2); transform_x_row_s(P2, s2); transform_x_row_s(P3, s2);
-        split_row(R0{}); split_row(R1{}); split_row(R2{});
-        yrow(R3{});                                  // row 3 goes through the split in slots 0..1 of the first step
-    }
+    // U fragments of (slot q, point px) of cin group c
+    auto load_u = [&](auto q_tag, auto px_tag, int c) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_tag)::value, px = decltype(px_tag)::value;
+        A2[px] = lds_read2_dup<(q * 4 + px) * 16 + 8>(ua[c]);
+        A1[px] = lds_read2_dup<(q * 4 + px) * 16>(ua[c]);
+    };
+    // patch row dy of the tile in ring slot SLOT: piece x
+    auto load_p = [&](f32x4 (&P)[4], auto dy_tag, auto x_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr int dy = decltype(dy_tag)::value, x = decltype(x_tag)::value, SLOT = decltype(slot_tag)::value;
+        P[x] = lds_read128<pa_off(dy, x) + SLOT * PLANE_BYTES>(pa0);
+    };
+    auto prologue = [&](auto slot_tag, auto first_slot_tag) __attribute__((always_inline)) {
+        static_for_h<0, 4>([&](auto x) __attribute__((always_inline)) {
+            load_p(P0, R0{}, x, slot_tag); load_p(P1, R1{}, x, slot_tag); load_p(P2, R2{}, x, slot_tag); load_p(P3, R3{}, x, slot_tag); });
+        static_for_h<0, 4>([&](auto px) __attribute__((always_inline)) { load_u(first_slot_tag, px, 0); });
+        lgkm_wait_p<0>(P0); lgkm_wait_p<0>(P1); lgkm_wait_p<0>(P2); lgkm_wait_p<0>(P3);
+        lgkm_wait_u<0>(A1[0], A2[0], A1[1], A2[1]); lgkm_wait_u<0>(A1[2], A2[2], A1[3], A2[3]);
+    };
+    // tile m0 sits in ring slot (G s0) mod 3; the first step that runs is S1O (slab at z = 0) or S0
+    if (first_zero) prologue(std::integral_constant<int, G % 3>{}, std::integral_constant<int, mh_first_slot(MH_S1O)>{});
+    else prologue(std::integral_constant<int, 0>{}, std::integral_constant<int, mh_first_slot(MH_S0)>{});
+    transform_x_row_s(P0, s2); transform_x_row_s(P1, s2); transform_x_row_s(P2, s2); transform_x_row_s(P3, s2);
+    split_row(R0{}); split_row(R1{}); split_row(R2{});
+    yrow(R3{});                                  // row 3 goes through the split in slots 0..1 of the first step
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = zero4; acc[1][i] = zero4; acc[2][i] = zero4; }
-    {
-        // U fragments of the first active row of the first step that runs
-        const unsigned fo = first_zero ? uh_row_off(mh_first_slot(MH_S1O)) : uh_row_off(mh_first_slot(MH_S0));
-#pragma unroll
-        for (int px = 0; px < 4; ++px) { A1[px] = ldsu(ua + fo + (unsigned)(px * UH_ROW_BYTES)); A2[px] = ldsu(ua + fo + (unsigned)(px * UH_ROW_BYTES + 1024)); }
-    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { resv[q] = zero4; ost[q] = zero4; }
 
     unsigned long long res_pl = (unsigned long long)res_n + (unsigned long long)(long long)(zb - 2 + s0) * HWR;     // plane zo of step s0
     unsigned long long out_pl = (unsigned long long)out_n + (unsigned long long)(long long)(zb - 2 + s0) * HWO;
-    in_pl += (unsigned long long)s0 * HWI;
+    unsigned long long in_pl = (unsigned long long)in_n + (unsigned long long)(long long)(zb - 1 + s0) * HWI;       // input plane of step s0 (cin group 0)
 
-    // One input plane: s = step index (input plane z = zb-1+s), PH = s mod 3; MODE as in conv16_wino_kernel.
+    // One micro-step: s = input plane index (z = zb-1+s), PH = s mod 3, C = cin group; MODE as in conv16_wino_kernel.
     // Slot q = row (py = q / 3, dz = 2 - q % 3): 8 MFMAs, each followed by a few single-issue instructions that run in its shadow
-    // (F: cvts, AccVGPR reads, LDS reads, DMA issue), then a block of packed adds / DOT ops (K).
-    //   input side, V row r of plane s+1 (its pieces are dead after slot 3r + 2):
-    //     K(3r+2) yrow   F(3r+3) h = cvt_pk(Y)   F(3r+4) l = fma_mix(Y - h)                        (r = 3 wraps into slots 0..1)
-    //     patch rows: P2 F(0), P0 F(1), x-transforms K(1) / K(2);  P1 F(4), K(4);  P3 F(9), K(10);  plane s+2 -> LDS: F(3)
-    //   output side, row r of the finished plane (its dz = 2 MFMAs ran in slot 3r): F(3r+2) AccVGPR reads, K(3r+2) A^T;
-    //     K(8) / K(11): epilogue of output rows 0 / 1 and the residual loads of the NEXT plane into the registers just consumed.
-    auto step = [&](auto ph_tag, int s, auto mode_tag) __attribute__((always_inline)) {
-        constexpr int PH = decltype(ph_tag)::value;
+    // (F: cvts, AccVGPR reads, LDS reads, DMA issue), then a block of packed adds / fma_mix ops (K).
+    //   input side, V row r of tile m+1 (its pieces are dead after slot 3r + 2):
+    //     K(3r+2) yrow   F(3r+3) h = cvt_pk(Y)   K(3r+4) l = fma_mix(Y - h)                        (r = 3 wraps into slots 0..1)
+    //     patch rows: P2 F(0), P0 F(1), x-transforms K(1) / K(2);  P1 F(4), K(5);  P3 F(9), K(10);  tile m+2 -> LDS: F(3)
+    //   output side (last cin group only), row r of the finished plane (its dz = 2 MFMAs ran in slot 3r): F(3r+2) AccVGPR reads,
+    //     K(3r+2) A^T;  K(8) / K(11): epilogue of output rows 0 / 1 and the residual loads of the NEXT plane.
+    //   LDS reads, all inline asm, in program order per slot: gaps 0, 1, 4, 5: one patch piece each (slots 0, 1, 4, 9 only);
+    //     gaps 2, 3, 6, 7: the two fragments of point px = 0, 1, 2, 3 of the NEXT active row.  Waits by count (steady state, MODE ALL):
+    //     before MFMA 0 of a slot: at most 4 + 2 [previous slot read patches] younger reads may be outstanding; before MFMA 4:
+    //     4 + 2 [this slot reads patches]; a patch row is used a slot after its reads: 12.  Head / tail modes wait for everything.
+    auto step = [&](auto ph_tag, auto c_tag, int s, auto mode_tag) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_tag)::value, C = decltype(c_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
-        constexpr bool FIN = MODE == MH_FIN;
-        constexpr unsigned slotN = (unsigned)((PH + 1) % 3) * PLANE_BYTES;   // plane s+1 (read)
-        constexpr unsigned slotW = (unsigned)((PH + 2) % 3) * PLANE_BYTES;   // plane s+2 (written)
+        constexpr bool FIN = MODE == MH_FIN, FIRST = C == 0, LAST = C == G - 1, EXACT = MODE == MH_ALL;
+        constexpr int TN = (G * PH + C + 1) % 3, TW = (G * PH + C + 2) % 3;      // ring slots of tile m+1 (read) / m+2 (written)
         constexpr int AF = PH;                                               // acc slot of the plane finished by dz = 2
         constexpr bool ZO = MODE == MH_ALL || MODE == MH_FIN;                // the finished plane zo = zb - 2 + s exists (s >= 2)
+        constexpr int NMODE = LAST ? mh_next_mode(MODE) : MODE;              // mode of the next micro-step
         const bool zo_ok = s >= 2;
-        const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok ? HWO : 0u);
-        // residual of the finished plane: requested in K(0) / K(3), eight slots ahead of its use; no load is left in flight across the
-        // step boundary (conv_wino_bf16.hip)
-        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res ? HWR : 0u);
-        res_pl += HWR; out_pl += HWO;
-        const bool in_ok = (unsigned)(zb + 1 + s) < (unsigned)a.D;
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc((const void*)(in_ok ? in_pl : (unsigned long long)in_n), in_ok ? HWI : 0u);
-        if (!FIN) in_pl += HWI;
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc((const void*)(zo_ok ? out_pl : (unsigned long long)out_n), zo_ok && LAST ? HWO : 0u);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc((const void*)(zo_ok ? res_pl : (unsigned long long)res_n), zo_ok && has_res && LAST ? HWR : 0u);
+        // tile m + 2 = (plane s + (C + 2) / G, cin group (C + 2) % G)
+        constexpr int DS2 = (C + 2) / G, C2 = (C + 2) % G;
+        const bool in_ok = (unsigned)(zb - 1 + s + DS2) < (unsigned)a.D;
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc((const void*)(in_ok ? in_pl + (unsigned long long)DS2 * HWI + 64ull * C2 : (unsigned long long)in_n), in_ok ? HWI - 64u * C2 : 0u);
+        if constexpr (LAST) { res_pl += HWR; out_pl += HWO; in_pl += HWI; }
         static_for_h<0, 12>([&](auto q_tag) __attribute__((always_inline)) {
             constexpr int q = decltype(q_tag)::value;
             constexpr int py = q / 3, dz = 2 - q % 3;
             constexpr int as = (PH + 2 - dz) % 3;
             constexpr bool active = mh_row_active(MODE, dz);
-            constexpr int qn = mh_next_slot(MODE, q) % 12;
-            const unsigned un = ua + uh_row_off(qn);
-            constexpr bool opens = dz == 0 || (MODE == MH_S1O && dz == 1);
+            // the next active row: in this micro-step (same cin group) or the first one of the next micro-step
+            constexpr int qraw = mh_next_slot(MODE, q);
+            constexpr bool wraps = qraw >= 12;
+            constexpr int qn = wraps ? mh_first_slot(NMODE) : qraw;
+            constexpr int cn = wraps ? (C + 1) % G : C;
+            constexpr bool opens = FIRST && (dz == 0 || (MODE == MH_S1O && dz == 1));
+            constexpr bool preads = !FIN && (q == 0 || q == 1 || q == 4 || q == 9);                 // this slot reads a patch row
+            constexpr bool pprev = !FIN && (q == 1 || q == 2 || q == 5 || q == 10);                  // the previous slot did
             using RS = std::integral_constant<int, (q / 3 + 3) % 4>;        // V row in the split pipeline during this slot
             using STG = std::integral_constant<int, q % 3>;                  // its stage (2: none)
+            using TNt = std::integral_constant<int, TN>;
+            using QN = std::integral_constant<int, qn>;
             // ---- F(q): MFMA i, then what runs in its shadow
             static_for_h<0, 8>([&](auto i_tag) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_tag)::value;
@@ -343,24 +404,26 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
                     // with weight +1 and carries the bias
                     constexpr int h = i / 4, tm = (i % 4) / 2, px = 2 * h + (i & 1);
                     constexpr int k = py * 4 + px;
+                    if constexpr (i == 0) lgkm_wait_u<EXACT ? 4 + 2 * (pprev ? 1 : 0) : 0>(A1[0], A2[0], A1[1], A2[1]);
+                    if constexpr (i == 4) lgkm_wait_u<EXACT ? 4 + 2 * (preads ? 1 : 0) : 0>(A1[2], A2[2], A1[3], A2[3]);
                     const f32x4 c = (opens && tm == 0) ? ((py == 1 && px == 1) ? bias4 : zero4) : acc[as][k];
                     acc[as][k] = mfma_f16(tm == 1 ? A2[px] : A1[px], B[k], c);
                     // the fragments of a point are dead behind its second MFMA: the same registers receive the next row's
-                    if constexpr (tm == 1 && !(PCC_WH_PROBE & 256)) {
-                        A2[px] = ldsu(un + (unsigned)(px * UH_ROW_BYTES + 1024));
-                        A1[px] = ldsu(un + (unsigned)(px * UH_ROW_BYTES));
-                    }
+                    if constexpr (tm == 1 && !(PCC_WH_PROBE & 256)) load_u(QN{}, std::integral_constant<int, px>{}, cn);
                 }
                 if constexpr (!FIN) {
-                    if constexpr (!(PCC_WH_PROBE & 32) && (STG::value == 0 || !PCC_WH_MIXK)) cvt_task(RS{}, STG{}, i_tag);
-                    if constexpr (q == 0 && i >= 4 && !(PCC_WH_PROBE & 512)) P2[i - 4] = ldsr(pa0 + pa_off(2, i - 4) + slotN);
-                    if constexpr (q == 1 && i >= 4 && !(PCC_WH_PROBE & 512)) P0[i - 4] = ldsr(pa0 + pa_off(0, i - 4) + slotN);
-                    if constexpr (q == 4 && i >= 4 && !(PCC_WH_PROBE & 512)) P1[i - 4] = ldsr(pa0 + pa_off(1, i - 4) + slotN);
-                    if constexpr (q == 9 && i >= 4 && !(PCC_WH_PROBE & 512)) P3[i - 4] = ldsr(pa0 + pa_off(3, i - 4) + slotN);
+                    if constexpr (!(PCC_WH_PROBE & 32) && (STG::value == 0 || (STG::value == 1 && !PCC_WH_MIXK))) cvt_task(RS{}, STG{}, i_tag);
+                    if constexpr (preads && (i == 0 || i == 1 || i == 4 || i == 5) && !(PCC_WH_PROBE & 512)) {
+                        using X = std::integral_constant<int, i < 2 ? i : i - 2>;
+                        if constexpr (q == 0) load_p(P2, R2{}, X{}, TNt{});
+                        if constexpr (q == 1) load_p(P0, R0{}, X{}, TNt{});
+                        if constexpr (q == 4) load_p(P1, R1{}, X{}, TNt{});
+                        if constexpr (q == 9) load_p(P3, R3{}, X{}, TNt{});
+                    }
                     if constexpr (q == 3 && i >= 2 && !(PCC_WH_PROBE & 2))
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(smem + slotW + (wave * 5 + i - 2) * 1024), 16, (int)rel[i - 2], 0, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(smem + TW * PLANE_BYTES + (wave * 5 + i - 2) * 1024), 16, (int)rel[i - 2], 0, 0, 0);
                 }
-                if constexpr (q % 3 == 2 && !(PCC_WH_PROBE & 64)) {
+                if constexpr (LAST && q % 3 == 2 && !(PCC_WH_PROBE & 64)) {
                     // AccVGPR reads of row q / 3 of the finished plane: two per MFMA gap
                     constexpr int r = q / 3;
 #pragma unroll
@@ -374,16 +437,15 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
                 if constexpr (q % 3 == 1 && PCC_WH_MIXK && !(PCC_WH_PROBE & 32))
                     static_for_h<0, 8>([&](auto j) __attribute__((always_inline)) { cvt_task(RS{}, ST1{}, j); });
                 if constexpr (!(PCC_WH_PROBE & 128)) {
-                    if constexpr (q == 1) transform_x_row_s(P2, s2);
-                    if constexpr (q == 2) { transform_x_row_s(P0, s2); yrow(R0{}); }
-                    if constexpr (q == 4) transform_x_row_s(P1, s2);
-                    if constexpr (q == 5) yrow(R1{});
+                    if constexpr (q == 1) { lgkm_wait_p<EXACT ? 12 : 0>(P2); transform_x_row_s(P2, s2); }
+                    if constexpr (q == 2) { lgkm_wait_p<EXACT ? 12 : 0>(P0); transform_x_row_s(P0, s2); yrow(R0{}); }
+                    if constexpr (q == 5) { lgkm_wait_p<EXACT ? 12 : 0>(P1); transform_x_row_s(P1, s2); yrow(R1{}); }
                     if constexpr (q == 8) yrow(R2{});
-                    if constexpr (q == 10) transform_x_row_s(P3, s2);
+                    if constexpr (q == 10) { lgkm_wait_p<EXACT ? 12 : 0>(P3); transform_x_row_s(P3, s2); }
                     if constexpr (q == 11) yrow(R3{});
                 }
             }
-            if constexpr (q % 3 == 2 && !(PCC_WH_PROBE & 64)) {
+            if constexpr (LAST && q % 3 == 2 && !(PCC_WH_PROBE & 64)) {
                 // A^T along x on row r of the finished plane, accumulate A^T along y
                 constexpr int r = q / 3;
                 const f32x4 m0 = {Mr[0], Mr[1], Mr[2], Mr[3]}, m1 = {Mr[4], Mr[5], Mr[6], Mr[7]}, m2 = {Mr[8], Mr[9], Mr[10], Mr[11]}, m3 = {Mr[12], Mr[13], Mr[14], Mr[15]};
@@ -393,7 +455,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
                 else if (r == 2) { S[0][0] = add4(S[0][0], r0); S[0][1] = add4(S[0][1], r1); S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
                 else { S[1][0] = sub4(S[1][0], r0); S[1][1] = sub4(S[1][1], r1); }
             }
-            if constexpr ((q == 8 || q == 11) && !(PCC_WH_PROBE & (64 | 4))) {
+            if constexpr (LAST && (q == 8 || q == 11) && !(PCC_WH_PROBE & (64 | 4))) {
                 // epilogue of output row oy (complete after reduction row 2 resp. 3): ReLU, un-scale + residual (one packed fma), clip, stores
                 constexpr int oy = q == 8 ? 0 : 1;
 #pragma unroll
@@ -411,19 +473,20 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
 #pragma unroll
                 for (int v = 2 * oy; v < 2 * oy + 2; ++v) buf_store4(rout, ost[v], ovo0, oso[v]);
             }
-            if constexpr ((q == 0 || q == 3) && !(PCC_WH_PROBE & 4)) {
+            if constexpr (LAST && (q == 0 || q == 3) && !(PCC_WH_PROBE & 4)) {
 #pragma unroll
                 for (int v = 2 * (q / 3); v < 2 * (q / 3) + 2; ++v) resv[v] = buf_load4(rres, rvo0, rso[v]);
             }
             // gfx950: a buffer_store_dwordx4 reads its data registers late (conv16_wino_kernel): keep them unwritten for one more slot
-            if constexpr (q == 9) { asm volatile("" ::"v"(ost[0])); asm volatile("" ::"v"(ost[1])); }
-            if constexpr (q == 0) { asm volatile("" ::"v"(ost[2])); asm volatile("" ::"v"(ost[3])); }
+            if constexpr (LAST && q == 9) { asm volatile("" ::"v"(ost[0])); asm volatile("" ::"v"(ost[1])); }
+            if constexpr (LAST && q == 0) { asm volatile("" ::"v"(ost[2])); asm volatile("" ::"v"(ost[3])); }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // the LDS-direct loads of plane s+2 (F(3)) must have landed before the barrier publishes them; younger: the residual loads of
-        // K(3) and the 4 stores of K(8) / K(11)
+        // the LDS-direct loads of tile m+2 (F(3)) must have landed before the barrier publishes them; younger (last cin group only):
+        // the residual loads of K(3) and the 4 stores of K(8) / K(11).  LDS reads stay in flight across the barrier.
         if (!FIN && !(PCC_WH_PROBE & 1)) {
-            __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6) expcnt(7) lgkmcnt(15)
+            if constexpr (LAST) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6) expcnt(7) lgkmcnt(15)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
             __syncthreads();
         }
     };
@@ -432,23 +495,29 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
     using P2t = std::integral_constant<int, 2>;
     using MAll = std::integral_constant<int, MH_ALL>;
     using MFin = std::integral_constant<int, MH_FIN>;
+    // one input plane = G micro-steps
+    auto plane = [&](auto ph_tag, int s, auto mode_tag) __attribute__((always_inline)) {
+        static_for_h<0, G>([&](auto c_tag) __attribute__((always_inline)) { step(ph_tag, c_tag, s, mode_tag); });
+    };
+    using CL = std::integral_constant<int, G - 1>;
 
-    if (first_zero) step(P1t{}, 1, std::integral_constant<int, MH_S1O>{});
+    if (first_zero) plane(P1t{}, 1, std::integral_constant<int, MH_S1O>{});
     else {
-        step(P0t{}, 0, std::integral_constant<int, MH_S0>{});
-        step(P1t{}, 1, std::integral_constant<int, MH_S1>{});
+        plane(P0t{}, 0, std::integral_constant<int, MH_S0>{});
+        plane(P1t{}, 1, std::integral_constant<int, MH_S1>{});
     }
     const int nloop = nsteps - (last_zero ? 1 : 0);
     for (int s = 2; s < nloop; s += 3) {
-        step(P2t{}, s, MAll{});
-        if (s + 1 < nloop) step(P0t{}, s + 1, MAll{});
-        if (s + 2 < nloop) step(P1t{}, s + 2, MAll{});
+        plane(P2t{}, s, MAll{});
+        if (s + 1 < nloop) plane(P0t{}, s + 1, MAll{});
+        if (s + 2 < nloop) plane(P1t{}, s + 2, MAll{});
     }
     if (last_zero) {
+        // the padding plane behind the volume: no matrix work; its last micro-step reduces and stores output plane D - 1
         const int sl = nsteps - 1, ph = sl % 3;
-        if (ph == 0) step(P0t{}, sl, MFin{});
-        else if (ph == 1) step(P1t{}, sl, MFin{});
-        else step(P2t{}, sl, MFin{});
+        if (ph == 0) step(P0t{}, CL{}, sl, MFin{});
+        else if (ph == 1) step(P1t{}, CL{}, sl, MFin{});
+        else step(P2t{}, CL{}, sl, MFin{});
     }
     // ---- max |out| of block n for the next layer's pre-scale (order-independent: atomicMax on non-negative fp32 bit patterns)
     if (a.amax_out != nullptr) pcc_amax_record(a.amax_out + (size_t)n * PCC_AMAX_SLOTS, mx, (int)blockIdx.x * 4 + wave);
@@ -485,9 +554,10 @@ int pcc_block_amax(pcc_ctx* ctx, const float* x, int N, size_t per_block, unsign
     return PCC_OK;
 }
 
-// ---- host: two-piece fp16 image of the Winograd-transformed weights.  Per (cin group, cout group): [slot q = 3 py + 2 - dz][px][operand][lane][8 fp16]
-//      operand 0 = [Uh c0..c3 | Uh c0..c3], operand 1 = [Ul | Ul];  cin = 16 cig + 4 (lane >> 4) + c, cout = 16 cog + (lane & 15);
-//      behind the pairs: PCC_WINO_UH_TAIL floats, [0] = su (the power of two all pieces were scaled by)
+// ---- host: two-piece fp16 image of the Winograd-transformed weights, lane-contiguous (the LDS layout: one linear copy per workgroup).
+//      [cout group][cin group][lane][slot q = 3 py + 2 - dz][px][4 h | 4 l fp16] + 8 B pad per lane;
+//      cin = 16 cig + 4 (lane >> 4) + c, cout = 16 cog + (lane & 15); behind the pairs: PCC_WINO_UH_TAIL floats, [0] = su (the power of
+//      two all pieces were scaled by)
 static inline unsigned short f16_bits(float v) {
     const _Float16 h = (_Float16)v;          // round to nearest even, denormals kept
     unsigned short b;
@@ -501,6 +571,7 @@ static inline float f16_value(unsigned short b) {
 }
 // u_f32: the fp32 Winograd image of conv_wino.hip ([cin group][cout group][48][64 lanes][4]) -> out: PCC_WINO_UH_FLOATS per pair + tail
 void pcc_wino_f16s_pack(int ngroups, const float* u_f32, float* out) {
+    static_assert(PCC_WINO_UH_FLOATS * 4 == UG_BYTES, "image size");
     const size_t nu = (size_t)ngroups * ngroups * 48 * 64 * 4;
     float umax = 0.f;
     for (size_t i = 0; i < nu; ++i) {
@@ -515,40 +586,39 @@ void pcc_wino_f16s_pack(int ngroups, const float* u_f32, float* out) {
         se = se < -100 ? -100 : se > 100 ? 100 : se;
         su = ldexpf(1.f, se);
     }
+    memset(out, 0, ((size_t)ngroups * ngroups * PCC_WINO_UH_FLOATS + PCC_WINO_UH_TAIL) * sizeof(float));
     unsigned short* o = reinterpret_cast<unsigned short*>(out);
-    for (int pair = 0; pair < ngroups * ngroups; ++pair)
-        for (int row = 0; row < 48; ++row)
-            for (int lane = 0; lane < 64; ++lane) {
-                unsigned short h[4], l[4];
-                for (int c = 0; c < 4; ++c) {
-                    const float x = u_f32[(((size_t)pair * 48 + row) * 64 + lane) * 4 + c] * su;      // exact
-                    h[c] = f16_bits(x);
-                    l[c] = f16_bits(x - f16_value(h[c]));                                              // the difference is exact
+    for (int cig = 0; cig < ngroups; ++cig)
+        for (int cog = 0; cog < ngroups; ++cog)
+            for (int row = 0; row < 48; ++row)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int dz = row / 16, py = (row / 4) % 4, px = row % 4, q = 3 * py + 2 - dz;
+                    unsigned short* d = o + ((size_t)(cog * ngroups + cig) * UG_BYTES + (size_t)lane * UL_LANE_BYTES + (size_t)(q * 4 + px) * 16) / 2;
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = u_f32[((((size_t)cig * ngroups + cog) * 48 + row) * 64 + lane) * 4 + c] * su;      // exact
+                        d[c] = f16_bits(x);
+                        d[4 + c] = f16_bits(x - f16_value(d[c]));                                                    // the difference is exact
+                    }
                 }
-                const int dz = row / 16, py = (row / 4) % 4, px = row % 4, orow = (3 * py + 2 - dz) * 4 + px;
-                unsigned short* a1 = o + ((((size_t)pair * 48 + orow) * 2 + 0) * 64 + lane) * 8;
-                unsigned short* a2 = o + ((((size_t)pair * 48 + orow) * 2 + 1) * 64 + lane) * 8;
-                for (int c = 0; c < 4; ++c) { a1[c] = h[c]; a1[4 + c] = h[c]; a2[c] = l[c]; a2[4 + c] = l[c]; }
-            }
-    float* tail = out + (size_t)ngroups * ngroups * PCC_WINO_UH_FLOATS;
-    for (int i = 0; i < PCC_WINO_UH_TAIL; ++i) tail[i] = 0.f;
-    tail[0] = su;
+    out[(size_t)ngroups * ngroups * PCC_WINO_UH_FLOATS] = su;
 }
 
-bool pcc_wino_f16s_covers(const pcc_conv_desc* d) { return d->Cin == 16 && d->Cout == 16; }
+bool pcc_wino_f16s_covers(const pcc_conv_desc* d) { return (d->Cin == 16 && d->Cout == 16) || (d->Cin == 32 && d->Cout == 32); }
 
 int pcc_conv_wino_f16s(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* uh_packed, const float* bias,
                        const float* residual, float* out, pcc_conv_ext* ext, hipStream_t st) {
-    PCC_REQUIRE(pcc_wino_eligible(d) && d->Cin == 16, "pcc_conv_wino_f16s: shape not covered");
+    PCC_REQUIRE(pcc_wino_eligible(d) && pcc_wino_f16s_covers(d), "pcc_conv_wino_f16s: shape not covered");
+    const int G = d->Cin / 16;
+    PCC_REQUIRE(G == 1 || !(d->flags & PCC_CONV_CLIP01), "pcc_conv_wino_f16s: the 32-channel kernel does not clip");
     WinoArgs a;
     a.in = in; a.bias = bias; a.res = residual; a.out = out;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
     a.nty = d->H / 16; a.ntx = d->W / 16;
     a.ocs = d->out_cstride ? d->out_cstride : d->Cout;
     a.oco = d->out_coffset;
-    a.nco = 1; a.ics = d->Cin; a.rcs = d->Cout; a.ico = 0; a.ncig = 1;
+    a.nco = G; a.ics = d->Cin; a.rcs = d->Cout; a.ico = 0; a.ncig = G;
     a.u = uh_packed; a.flags = d->flags;
-    a.utail = uh_packed + PCC_WINO_UH_FLOATS;
+    a.utail = uh_packed + (size_t)G * G * PCC_WINO_UH_FLOATS;
     a.amax_out = ext ? ext->out_amax : nullptr;
     if (ext) ext->out_recorded = ext->out_amax != nullptr;
     if (ext && ext->in_amax) a.amax_in = ext->in_amax;
@@ -558,17 +628,20 @@ int pcc_conv_wino_f16s(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
         { const int rc = pcc_block_amax(ctx, in, d->N, (size_t)d->D * d->H * d->W * d->Cin, am, st); if (rc != PCC_OK) return rc; }
         a.amax_in = am;
     }
-    const int base = d->N * a.nty * a.ntx;
+    const int base = d->N * a.nty * a.ntx * G;
     int zs = 1;
-    while (base * zs < ctx->num_cu && d->D % (zs * 2) == 0 && d->D / (zs * 2) >= 8) zs *= 2;
+    const int min_zlen = G >= 2 ? 4 : 8;
+    while (base * zs < ctx->num_cu && d->D % (zs * 2) == 0 && d->D / (zs * 2) >= min_zlen) zs *= 2;
     a.zsplit = zs; a.zlen = d->D / zs;
     const int nwg = base * zs;
     typedef void (*kern_t)(WinoArgs, int);
-    static const kern_t kerns[4] = {conv16_wino_f16s_kernel<false, false>, conv16_wino_f16s_kernel<true, false>,
-                                    conv16_wino_f16s_kernel<false, true>, conv16_wino_f16s_kernel<true, true>};
-    const kern_t kern = kerns[((d->flags & PCC_CONV_RELU) ? 1 : 0) + ((d->flags & PCC_CONV_CLIP01) ? 2 : 0)];
-    { const int rc = pcc_enable_big_lds((const void*)kern, LDS_BYTES_H); if (rc != PCC_OK) return rc; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), LDS_BYTES_H, st, a, nwg);
+    static const kern_t kerns[6] = {conv16_wino_f16s_kernel<false, false, 1>, conv16_wino_f16s_kernel<true, false, 1>,
+                                    conv16_wino_f16s_kernel<false, true, 1>, conv16_wino_f16s_kernel<true, true, 1>,
+                                    conv16_wino_f16s_kernel<false, false, 2>, conv16_wino_f16s_kernel<true, false, 2>};
+    const kern_t kern = G == 1 ? kerns[((d->flags & PCC_CONV_RELU) ? 1 : 0) + ((d->flags & PCC_CONV_CLIP01) ? 2 : 0)] : kerns[4 + ((d->flags & PCC_CONV_RELU) ? 1 : 0)];
+    const int lds = f16s_lds_bytes(G);
+    { const int rc = pcc_enable_big_lds((const void*)kern, lds); if (rc != PCC_OK) return rc; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds, st, a, nwg);
     PCC_CHECK_HIP(hipGetLastError());
     return PCC_OK;
 }
