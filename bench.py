@@ -109,6 +109,61 @@ def c3p_step_flops(res, batch, num_cu=256, winograd=True, split=False):
     return alg, ex
 
 
+def step_layers(res, batch):
+    """Every conv launch of one c3p step (compress graph + decompress graph of one chunk), in the order of
+    /root/reference/src/model_transforms.py:112-158: (transform id, layer index, calls per step, pcc_conv_desc fields, has residual)."""
+    from pcc_geo_cnn_v2_amd import _lib as L
+    rows = []
+
+    def block(tid, first, d_in, specs, calls):
+        d = d_in
+        for i, (cin, cout, k, s, tr, res_add) in enumerate(specs):
+            rows.append(dict(transform=tid, layer=first + i, calls=calls, cin=cin, cout=cout, k=k, stride=s, transposed=tr, d_in=d, residual=res_add))
+            d = d * s if tr else -(-d // s)
+        return d
+
+    def blk(f_in, f, tr):
+        return [(f_in, f, 3, 2, tr, False), (f, f, 3, 1, tr, False), (f, f, 3, 1, tr, True)]
+    block(L.PCC_NET_ANALYSIS_PROGRESSIVE_V2, 0, res, blk(1, 16, 0) + blk(16, 32, 0) + blk(32, 64, 0) + [(64, 64, 3, 1, 0, False)], 1)
+    block(L.PCC_NET_HYPER_ANALYSIS, 0, res // 8, [(64, 64, 3, 1, 0, False), (64, 64, 3, 2, 0, False), (64, 64, 3, 1, 0, False)], 1)
+    block(L.PCC_NET_HYPER_SYNTHESIS, 0, res // 16, [(64, 64, 3, 1, 1, False), (64, 64, 3, 2, 1, False), (64, 64, 3, 1, 1, False)], 2)
+    block(L.PCC_NET_SYNTHESIS_PROGRESSIVE_V2, 0, res // 8, blk(64, 64, 1) + blk(64, 32, 1) + blk(32, 16, 1) + [(16, 1, 3, 1, 1, False)], 2)
+    return rows
+
+
+def layer_roofs(ctx, row, batch, ms):
+    """One row of roofline.step.layers: the layer's algorithmic HBM bytes (fp32 input + output + residual, unfused) and the multiply-adds
+    its kernel family executes, each against the roof of the unit that does it, for a measured launch time."""
+    import ctypes
+    from pcc_geo_cnn_v2_amd import _lib as L
+    d_in, cin, cout, k, s, tr = row['d_in'], row['cin'], row['cout'], row['k'], row['stride'], row['transposed']
+    d_out = d_in * s if tr else -(-d_in // s)
+    desc = L.ConvDesc(N=batch, D=d_in, H=d_in, W=d_in, Cin=cin, Cout=cout, k=k, stride=s, transposed=tr,
+                      flags=L.PCC_CONV_BIAS | L.PCC_CONV_RELU | (L.PCC_CONV_ADD if row['residual'] else 0))
+    buf = ctypes.create_string_buffer(96)
+    L.check(L.lib().pcc_conv_kernel_family(ctx.handle, ctypes.byref(desc), buf, 96), 'pcc_conv_kernel_family')
+    fam = buf.value.decode()
+    grid = d_in if (tr and s == 2) else d_out                    # the grid the 27 taps are applied on (SURVEY.md 8d)
+    macs = float(batch) * grid ** 3 * k ** 3 * cin * cout
+    nbytes = 4.0 * batch * (d_in ** 3 * cin + d_out ** 3 * cout * (2 if row['residual'] else 1))
+    ex = macs
+    if fam.startswith('conv16_wino'):
+        ex = macs * wino_exec_factor(16 if 'f16s' in fam else cin, d_in, batch, ctx.num_cu)
+    if 'fp16 x 2' in fam:
+        pipe, peak, mult = 'f16 MFMA (4 product terms per fp32 multiply-add)', PEAK_BF16_MFMA, 4.0
+    elif 'bf16 x 3' in fam:
+        pipe, peak, mult = 'bf16 MFMA (6 product terms per fp32 multiply-add)', PEAK_BF16_MFMA, 6.0
+    elif 'VALU' in fam or 'generic' in fam:
+        pipe, peak, mult = 'fp32 VALU', PEAK_FP32_MFMA, 1.0
+    else:
+        pipe, peak, mult = 'fp32 MFMA', PEAK_FP32_MFMA, 1.0
+    t = ms * 1e-3
+    hbm_frac = nbytes / t / 1e9 / PEAK_HBM
+    pipe_frac = 2.0 * ex * mult / t / 1e12 / peak
+    return dict(kernel_family=fam, algorithmic_bytes=nbytes, hbm_frac_of_8tbs=hbm_frac, pipe=pipe, executed_pipe_flops=2.0 * ex * mult,
+                pipe_frac_of_peak=pipe_frac, frac_of_own_roof=max(hbm_frac, pipe_frac), bound='hbm' if hbm_frac >= pipe_frac else 'mfma'), nbytes, 2.0 * ex * mult, peak
+
+
 def synthetic_weights(model, seed=42):
     from pcc_geo_cnn_v2_amd.entropy_models import EntropyBottleneck
     w = {k: v for k, v in model.get_weights().items() if not k.startswith('entropy_bottleneck/')}
@@ -488,6 +543,22 @@ def main():
                                   'traffic': None, 'algorithmic_bytes_per_launch': bytes2, 'avg_launch_ms': avg2, 'launches_timed': len(k2)}}
         del m2, x2
 
+    # roofline.step: where the whole step is.  Every conv layer of the four transforms is timed in turn with the
+    # library's HIP-event hook (one layer per pass of 3 steps, after the timed region, same process, same clock state as the pipeline
+    # keeps running) and priced against its own roof; what the list does not cover (quantisers, packing, threshold + compaction,
+    # the host coder's shadow, queue gaps, minus the overlap of the encoder and decoder streams) is the residual row.
+    step_profile = None
+    if world == 1 and args.precision == 'fp32' and args.workload == 'configs1' and not os.environ.get('PCC_BENCH_NO_STEP_PROFILE'):
+        rows = step_layers(RES, args.chunk)
+        for r in rows:
+            ops.profile_select(ctx, r['transform'], r['layer'], stride=1)
+            run(3)
+            torch.cuda.synchronize(device)
+            k_ms = ops.profile_read(ctx)
+            ops.profile_select(ctx, -1, -1)
+            r['launch_ms'] = [float(v) for v in k_ms]
+        step_profile = rows
+
     if rank == 0:
         value = tot_blocks / elapsed
         flops_launch = 2.0 * args.chunk * RES ** 3 * 27 * 16 * 16     # algorithmic flops of one dominant launch
@@ -500,7 +571,16 @@ def main():
         if winograd:
             # F(2x2,3x3) in x-y (16 instead of 36 multiplies per 2x2 outputs and z tap); padding planes skipped
             exec_flops = flops_launch * wino_exec_factor(16, RES, args.chunk, ctx.num_cu)
-            if split:
+            f16s = split and not (num_sw & L.PCC_NUM['no_f16s'])
+            if f16s:
+                dom_kernel = ('conv16_wino_f16s_kernel<relu, G = 1> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the '
+                              'decoder; layer 7 runs the same kernel: 4 launches per step)')
+                dom_note = ('two-piece fp16 Winograd (round 6): every fp32 operand = h + l fp16 pieces under an exact power-of-two pre-scale (weights: per layer; '
+                            'activations: per 64^3 block, from the max |x| its producer recorded), all four product terms in two v_mfma_f32_16x16x32_f16 per row '
+                            '(fp32 accumulate), operand error 2^-22 (tests/test_conv_gpu.py: the same gates as the exact-fp32 kernel).  Nearest hardware roof: HBM '
+                            '(achieved/frac = algorithmic bytes: input + residual + output, / HIP-event launch time / 8 TB/s); `mfma` restates it against the matrix '
+                            'peaks; PCC_NO_F16S=1 gives the three-piece bf16 kernel of round 4, PCC_NO_SPLIT=1 the exact-fp32 line')
+            elif split:
                 dom_kernel = ('conv16_wino_bf16_kernel<relu> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the '
                               'decoder; layer 7 runs the same kernel: 4 launches per step)')
                 dom_note = ('split-bf16 Winograd: every fp32 operand = three bf16 pieces, six product terms in three v_mfma_f32_16x16x32_bf16 per row (fp32 '
@@ -533,13 +613,14 @@ def main():
                                                 'launch time / 8 TB/s.  NOT comparable with rounds 1-3, whose frac was executed fp32-MFMA flops / 157.3 TFLOP/s '
                                                 '(that figure is kept as mfma.fp32_equivalent_over_fp32_mfma_peak; the bf16-pipe utilisation is '
                                                 'mfma.frac_of_bf16_mfma_peak)'),
-                            'mfma': {'executed_bf16_flops_per_launch': 6.0 * exec_flops, 'executed_bf16_tflops': 6.0 * achieved_exec,
-                                     'frac_of_bf16_mfma_peak': 6.0 * achieved_exec / PEAK_BF16_MFMA,
+                            'mfma': {'executed_bf16_flops_per_launch': (4.0 if f16s else 6.0) * exec_flops, 'executed_bf16_tflops': (4.0 if f16s else 6.0) * achieved_exec,
+                                     'frac_of_bf16_mfma_peak': (4.0 if f16s else 6.0) * achieved_exec / PEAK_BF16_MFMA,
                                      'fp32_equivalent_flops_per_launch': exec_flops, 'fp32_equivalent_tflops': achieved_exec,
                                      'fp32_equivalent_over_fp32_mfma_peak': achieved_exec / PEAK_FP32_MFMA,
                                      'algorithmic_flops_per_launch': flops_launch, 'algorithmic_tflops': achieved,
                                      'algorithmic_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA,
-                                     'note': 'three bf16 MFMAs of K = 32 replace four fp32 MFMAs of K = 4 per row: 6x the multiply-adds of the fp32 kernel, on a 16x faster pipe'},
+                                     'note': ('two f16 MFMAs of K = 32 replace four fp32 MFMAs of K = 4 per row: 4x the multiply-adds of the fp32 kernel (the executed_bf16_* keys hold f16-pipe figures: same 2.5 PF peak)'
+                                              if f16s else 'three bf16 MFMAs of K = 32 replace four fp32 MFMAs of K = 4 per row: 6x the multiply-adds of the fp32 kernel, on a 16x faster pipe')},
                             'note': dom_note}
         else:
             dom_roofline = {'bound': 'mfma', 'kernel': dom_kernel,
@@ -567,13 +648,14 @@ def main():
                        'device_allocations_in_timed_region': dev_allocs,
                        'cpu_quota_throttled_periods_in_timed_region': None if thr0 is None else thr1 - thr0, 'sharding': f'blocks x{world}',
                        'weights': f'synthetic Glorot-uniform, gains {GAIN_ANALYSIS}/{GAIN_SYNTHESIS}, seed 42',
-                       'mfma_operand_split': (('fp32 operands as 3 bf16 pieces (8+8+8 significand bits, round-to-nearest residuals), product terms hh hm mh hl mm lh in '
-                                               '3 x v_mfma_f32_16x16x32_bf16 per fp32 product row, fp32 accumulate, fixed order.  Per 32-block step (encode + decode): 16-channel '
-                                               'Winograd layers (6 launches, conv_wino_bf16.hip); direct k3 stride-1 64->64 @16^3 (4), 32->32 @16^3 (2), 64->64 @8^3 (5) and '
-                                               'Conv3DTranspose stride 2 64->64 / 64->32 (2 + 2) (conv_split.hip); Conv3DTranspose stride 2 32->16 (2, conv_tr2m_bf16.hip).  '
-                                               'Exact fp32 MFMA: 32->32 @32^3 Winograd (4: its split weights, 96 KB per cin group, do not fit LDS beside the tile ring), the '
-                                               'stride-2 forward layers, the 4^3 grids, first and last layer.  PCC_NO_SPLIT=1: exact fp32 MFMA everywhere')
-                                              if split and args.precision == 'fp32' else None),
+                       'mfma_operand_split': (('Two forms, fp32 accumulate in a fixed order in both.  (a) two fp16 pieces (11 + 11 significand bits) under an exact '
+                                               'power-of-two pre-scale -- weights per layer, activations per 64^3 block from the max |x| recorded by the producing kernel -- '
+                                               'all four product terms in 2 x v_mfma_f32_16x16x32_f16 per product row: the Winograd layers, 16 -> 16 @64^3 / @32^3 (6 launches '
+                                               'per 32-block step) and 32 -> 32 @32^3 (4) (conv_wino_f16s.hip, round 6).  (b) three bf16 pieces (8 + 8 + 8 bits), terms hh hm '
+                                               'mh hl mm lh in 3 x v_mfma_f32_16x16x32_bf16: direct k3 stride-1 64->64 @16^3 (4), 32->32 @16^3 (2), 64->64 @8^3 (5), '
+                                               'Conv3DTranspose stride 2 64->64 / 64->32 (2 + 2) (conv_split.hip) and 32->16 (2, conv_tr2m_bf16.hip).  Exact fp32 MFMA: the '
+                                               'stride-2 forward layers, the 4^3 grids, first and last layer.  PCC_NO_F16S=1: (a) -> bf16 x 3 / exact fp32; PCC_NO_SPLIT=1: '
+                                               'exact fp32 MFMA everywhere') if split and args.precision == 'fp32' else None),
                        'executed_flops_note': ('executed = fp32-equivalent multiply-adds the kernels perform (Winograd layers 16/36 of the taps, direct layers all); with '
                                                'mfma_operand_split most of them are issued as bf16 MFMAs, so the _executed fraction below is a work figure relative to the fp32 '
                                                'pipe, not the utilisation of one pipe') if split and args.precision == 'fp32' else None,
@@ -595,6 +677,31 @@ def main():
                                   'output / HIP-event launch time; HBM3E peak 8 TB/s, ~6.3 TB/s achievable (MI355X_MICROARCH.md)'}
                          if args.precision == 'fp16' else dom_roofline),
         }
+        if step_profile:
+            ms_step = 1e3 * elapsed / args.steps
+            names = {L.PCC_NET_ANALYSIS_PROGRESSIVE_V2: 'analysis', L.PCC_NET_HYPER_ANALYSIS: 'hyper_analysis',
+                     L.PCC_NET_HYPER_SYNTHESIS: 'hyper_synthesis', L.PCC_NET_SYNTHESIS_PROGRESSIVE_V2: 'synthesis'}
+            layers, tot_us, tot_bytes, pipe_s = [], 0.0, 0.0, 0.0
+            for r in step_profile:
+                if not r['launch_ms']:
+                    continue
+                med = float(np.median(r['launch_ms']))
+                roofs, nbytes, pflops, peak = layer_roofs(ctx, r, args.chunk, med)
+                tot_us += 1e3 * med * r['calls']; tot_bytes += nbytes * r['calls']; pipe_s += pflops / (peak * 1e12) * r['calls']
+                layers.append(dict(layer=f"{names[r['transform']]}/{r['layer']}", shape=f"{r['cin']}->{r['cout']} k{r['k']} s{r['stride']}{' T' if r['transposed'] else ''} @{r['d_in']}^3"
+                                   + (' +res' if r['residual'] else ''), launches=r['calls'], median_us=1e3 * med, share_of_step=1e3 * med * r['calls'] / (1e3 * ms_step), **roofs))
+            layers.sort(key=lambda e: -e['share_of_step'])
+            dom_roofline['step'] = {
+                'ms_per_step': ms_step, 'conv_layers_sum_ms': tot_us / 1e3, 'conv_launches_per_step': sum(r['calls'] for r in step_profile),
+                'residual_ms': ms_step - tot_us / 1e3,
+                'residual_is': 'ms_per_step - sum(median launch time x launches): element-wise / packing / threshold kernels, queue gaps and host shadow, '
+                               'MINUS whatever the encoder and decoder streams overlap (can be negative)',
+                'list_covers_frac_of_step': tot_us / 1e3 / ms_step,
+                'unfused_algorithmic_bytes_per_step': tot_bytes, 'hbm_frac_whole_step': tot_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM,
+                'time_if_every_layer_ran_at_6300_gbs_ms': tot_bytes / 6.3e12 * 1e3,
+                'time_if_every_multiply_ran_at_its_pipe_peak_ms': pipe_s * 1e3, 'pipe_frac_whole_step': pipe_s * 1e3 / ms_step,
+                'how': 'HIP events around one layer per pass (3 steps each, after the timed region, pipeline running); kernel_family from pcc_conv_kernel_family',
+                'layers': layers}
         out['ab_exact_fp32'] = ab_exact
         out['secondary'] = secondary
         out['multi_gpu'] = multi

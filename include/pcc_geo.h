@@ -130,6 +130,9 @@ size_t pcc_conv_packed_floats(const pcc_conv_desc* d);
 /* HOST-side repack of a Keras-layout kernel into MFMA fragment order (done once at model load,
  * replaces saver.restore's variable placement, src/compress_octree.py:90-92). */
 int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w_keras_host, float* packed_host);
+/* Name of the kernel family pcc_conv3d takes for this descriptor on this context (w_packed given), e.g. "conv16_wino_f16s (...)":
+ * written NUL-terminated into buf (truncated to cap).  Diagnostic: bench.py prints it beside every layer's time.             */
+int pcc_conv_kernel_family(pcc_ctx* ctx, const pcc_conv_desc* d, char* buf, int32_t cap);
 /* `w` (device, Keras layout) is used by the generic path, `w_packed` (device, may be NULL) by the
  * MFMA path; `bias`/`residual` may be NULL when the matching flag is clear.  `residual` has the
  * shape of `out` with channel stride Cout. */

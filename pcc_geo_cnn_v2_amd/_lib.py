@@ -17,7 +17,7 @@ PCC_ROUND_FLOOR_HALF, PCC_ROUND_HALF_EVEN = 0, 1
 
 EXPORTS = [
     'pcc_abi_version', 'pcc_last_error', 'pcc_ctx_create', 'pcc_ctx_destroy', 'pcc_ctx_num_cu', 'pcc_ctx_get_numerics', 'pcc_ctx_set_numerics',
-    'pcc_conv_out_dims', 'pcc_conv_mfma_supported', 'pcc_conv_packed_floats', 'pcc_conv_pack_weights',
+    'pcc_conv_out_dims', 'pcc_conv_mfma_supported', 'pcc_conv_packed_floats', 'pcc_conv_pack_weights', 'pcc_conv_kernel_family',
     'pcc_conv3d', 'pcc_quantize', 'pcc_dequantize', 'pcc_scale_to_index', 'pcc_threshold_compact',
     'pcc_threshold_scratch_ints', 'pcc_voxelize', 'pcc_focal_loss', 'pcc_focal_scratch_floats',
     'pcc_symbols_tiles', 'pcc_symbols_pack', 'pcc_symbols_unpack',
@@ -94,6 +94,7 @@ def lib():
     L.pcc_conv_mfma_supported.argtypes = [C.POINTER(ConvDesc)]
     L.pcc_conv_packed_floats.argtypes = [C.POINTER(ConvDesc)]
     L.pcc_conv_packed_floats.restype = sz
+    L.pcc_conv_kernel_family.argtypes = [vp, C.POINTER(ConvDesc), C.c_char_p, i32]
     L.pcc_conv_pack_weights.argtypes = [C.POINTER(ConvDesc), vp, vp]
     L.pcc_conv3d.argtypes = [vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     L.pcc_quantize.argtypes = [vp, vp, vp, vp, vp, sz, i32, i32, vp]

@@ -1896,6 +1896,40 @@ bool pcc_conv_wants_amax(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     return k3s1_route(ctx, d) == 4;
 }
 
+// The kernel family pcc_conv3d takes for a layer on this context (same tests, same order as the dispatch below): what bench.py prints
+// beside every layer's time, and what a maintainer asks when two builds disagree in the last bits.
+PCC_API int pcc_conv_kernel_family(pcc_ctx* ctx, const pcc_conv_desc* d, char* buf, int32_t cap) {
+    PCC_REQUIRE(ctx && d && buf && cap > 0, "pcc_conv_kernel_family: NULL argument");
+    const char* name = "generic (reference-order fp32 FMA chain)";
+    const Plan p = make_plan(d);
+    const int ci = d->Cin, co = d->Cout, k = d->k;
+    if (d->impl == PCC_IMPL_GENERIC || p.kind == K_NONE) {
+    } else if ((d->flags & (PCC_CONV_IN16 | PCC_CONV_RES16)) && p.kind != K_COUT1M) name = "conv_f16 (fp16 storage, f16 MFMA)";
+    else if (p.kind == K_FWD) {
+        name = (d->flags & PCC_CONV_F16) ? "conv_fwd (f16 MFMA)" : "conv_fwd (exact fp32 MFMA)";
+        if (pcc_wino_channels(ci, co) && k == 3 && (p.flip ? 1 : d->stride) == 1) {
+            switch (k3s1_route(ctx, d)) {
+                case 1: name = (ctx->num(PCC_NUM_SPLIT_MFMA32) || (!ctx->num(PCC_NUM_SPLIT_MFMA16) && ci == 32)) && d->W != 8 ? "conv_k3s1_split32 (direct, bf16 x 3, 32x32x16 MFMA)" : "conv_k3s1_split (direct, bf16 x 3, 16x16x32 MFMA)"; break;
+                case 2: name = "conv16_wino (Winograd, exact fp32 MFMA)"; break;
+                case 3: name = "conv16_wino_bf16 (Winograd, bf16 x 3)"; break;
+                case 4: name = "conv16_wino_f16s (Winograd, fp16 x 2 under a per-block pre-scale)"; break;
+                default: break;
+            }
+        }
+    } else if (p.kind == K_TR2) {
+        name = "conv_tr2 (exact fp32 MFMA)";
+        if (k == 3 && d->impl == PCC_IMPL_AUTO && !ctx->num(PCC_NUM_NO_TR2M) && pcc_tr2m_f16_covers(d)) name = "conv_tr2m_f16 (z march, f16 MFMA)";
+        else if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
+            name = "conv_tr2_split (parity classes, bf16 x 3)";
+        else if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d)))
+            name = pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2) ? "conv_tr2m_bf16 (z march, bf16 x 3)" : "conv_tr2m (z march, exact fp32 MFMA)";
+    } else if (p.kind == K_CIN1) name = "conv_cin1 (exact fp32 MFMA)";
+    else if (p.kind == K_COUT1M) name = "conv_cout1_mfma (exact fp32 MFMA)";
+    else if (p.kind == K_COUT1) name = "conv_cout1 (fp32 VALU)";
+    snprintf(buf, (size_t)cap, "%s", name);
+    return PCC_OK;
+}
+
 int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_packed, const float* bias,
                         const float* residual, float* out, const pcc_thr_fuse* fuse, bool* fused, pcc_conv_ext* ext, hipStream_t st) {
     if (fused) *fused = false;

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): rocprofv3 evidence for profiles/.  Usage: tools/profile_round.sh <tag>
 # No trace domain other than --kernel-trace is ever combined with --pmc (gpurun refuses that), counters in separate passes.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -27,6 +27,7 @@ TRACE_CMD="python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondar
 echo "PCC_BENCH_NO_PRIME=1 $TRACE_CMD" > $OUT/trace_cmd.txt; echo 15 > $OUT/trace_steps.txt
 PCC_BENCH_NO_PRIME=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 180 python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-ab > $OUT/bench_profiled.log 2>&1
 export PCC_NO_SPLIT=1; pmc wino16_fp32 32 64 16 16 3 1 1 res; unset PCC_NO_SPLIT
+export PCC_NO_F16S=1; pmc wino16_bf16 32 64 16 16 3 1 1 res; unset PCC_NO_F16S
 pmc cin32 32 32 32 32 3 1 1 res
 pmc cin64 32 16 64 64 3 1 1 res
 pmc tr2m 32 32 32 16 3 2 1

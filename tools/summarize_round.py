@@ -23,11 +23,13 @@ PEAK_TF, HBM_TBS = 157.3, 8.0
 B = 32
 # key -> (kernel name fragment, description, algorithmic flops per launch, executed-MFMA flops per launch (None = counter), algorithmic bytes, bound)
 KERNELS = {
-    'wino16': ('conv16_wino_bf16_kernel', 'Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32 (split-bf16 Winograd F(2x2,3x3) x-y + direct z, conv_wino_bf16.hip)',
+    'wino16': ('conv16_wino_f16s_kernel<true, false, 1>', 'Conv3DTranspose 16->16 k3 s1 @64^3 + residual, batch 32 (two-piece fp16 Winograd F(2x2,3x3) x-y + direct z, conv_wino_f16s.hip)',
                2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'hbm'),
     'wino16_fp32': ('conv16_wino_kernel', 'the same layer on the exact-fp32 MFMA Winograd kernel (PCC_NO_SPLIT=1, conv_wino.hip): the A/B line of the split path',
                     2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'mfma'),
-    'cin32': ('conv16_wino_cin_kernel<true, 2>', 'Conv3DTranspose 32->32 k3 s1 @32^3 + residual, batch 32 (Winograd, cin groups inside the z march)',
+    'wino16_bf16': ('conv16_wino_bf16_kernel', 'the same layer on the three-piece bf16 kernel of round 4 (PCC_NO_F16S=1, conv_wino_bf16.hip)',
+                    2.0 * B * 64 ** 3 * 27 * 16 * 16, B * 64 ** 3 * 16 * 4 * 3, 'hbm'),
+    'cin32': ('conv16_wino_f16s_kernel<true, false, 2>', 'Conv3DTranspose 32->32 k3 s1 @32^3 + residual, batch 32 (two-piece fp16 Winograd, cin groups inside the z march; round 5: conv16_wino_cin_kernel<2>, exact fp32)',
               2.0 * B * 32 ** 3 * 27 * 32 * 32, B * 32 ** 3 * 32 * 4 * 3, 'mfma'),
     'cin64': ('conv_k3s1_split_kernel<64, 2', 'Conv3DTranspose 64->64 k3 s1 @16^3 + residual, batch 32 (direct, split-bf16 operands, conv_split.hip; round 3: conv16_wino_cin_kernel<4>)',
               2.0 * B * 16 ** 3 * 27 * 64 * 64, B * 16 ** 3 * 64 * 4 * 3, 'mfma'),
@@ -66,7 +68,7 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
     fetch = pmc.get('FETCH_SIZE', float('nan')) * 1024 * 2      # KB -> B, x2: gfx950 FETCH_SIZE counts 64 B per 128 B request (MI355X_MICROARCH.md)
     write = pmc.get('WRITE_SIZE', float('nan')) * 1024
     exec_flops = pmc.get('SQ_INSTS_VALU_MFMA_MOPS_F32', float('nan')) * 512
-    bf16 = key in ('wino16', 'cin64', 'tr2m', 'tr2g', 'fwd64_8')
+    bf16 = key in ('wino16', 'wino16_bf16', 'cin32', 'cin64', 'tr2m', 'tr2g', 'fwd64_8')
     if bf16:     # bf16 MFMAs: v_mfma_f32_16x16x32_bf16 = 16384 flops each (SQ_INSTS_MFMA counts instructions per wave)
         exec_flops = pmc.get('SQ_INSTS_MFMA', float('nan')) * 16384
     simd_cycles = pmc.get('GRBM_GUI_ACTIVE', float('nan')) / 8 * 1024
@@ -74,7 +76,7 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
            'launch_us_unprofiled_min': t_min, 'launch_us_unprofiled_median': t_med,
            'launch_us_in_counter_pass': sum(dur) / max(len(dur), 1),
            'algorithmic_flops_per_launch': alg_flops, 'executed_mfma_flops_per_launch': exec_flops,
-           'mfma_pipe': 'bf16 (split operands: 6x the multiply-adds of the fp32 kernel)' if bf16 else 'fp32',
+           'mfma_pipe': ('f16 (two-piece operands: 4x the multiply-adds of the fp32 kernel)' if key in ('wino16', 'cin32') else 'bf16 (split operands: 6x the multiply-adds of the fp32 kernel)') if bf16 else 'fp32',
            'executed_tflops': exec_flops / (t_med * 1e-6) / 1e12, 'executed_frac_of_pipe_peak': exec_flops / (t_med * 1e-6) / 1e12 / (2500.0 if bf16 else PEAK_TF),
            'algorithmic_tflops': alg_flops / (t_med * 1e-6) / 1e12,
            'mfma_busy_frac_of_simd_cycles': pmc.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) / simd_cycles,
@@ -90,7 +92,7 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
     rows.append(out)
     if key == 'wino16':
         import hashlib
-        ksrc = 'conv_wino_bf16.hip'
+        ksrc = 'conv_wino_f16s.hip'
         data = open(os.path.join(root, 'pcc_geo_cnn_v2_amd', 'csrc', ksrc), 'rb').read()
         out['executed_frac_of_bf16_mfma_peak'] = out['executed_tflops'] / 2500.0
         traffic_json = dict(out, kernel_source=ksrc, kernel_source_sha1=hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest(), method='rocprofv3 --pmc, one pass per counter group, on tools/bench_one.py 32 64 16 16 3 1 1 res; FETCH_SIZE doubled per '
@@ -100,10 +102,10 @@ if TRAFFIC_ONLY:
     sys.exit(0)
 json.dump(rows, open(os.path.join(dst, f'{tag}_kernel_counters.json'), 'w'), indent=1)
 # the dominant kernel inside the traced bench (its 64^3 launches = the (kernel, grid) row with the largest total among its rows)
-dom_rows = [(k, v) for k, v in trace_stats.items() if 'conv16_wino_bf16' in k[0] or 'conv16_wino2_bf16' in k[0]]
+dom_rows = [(k, v) for k, v in trace_stats.items() if 'conv16_wino_f16s_kernel<true, false, 1>' in k[0] or 'conv16_wino_bf16' in k[0]]
 dom_key, dom = max(dom_rows, key=lambda kv: kv[1]['total']) if dom_rows else (None, None)
 DOM_BYTES = 3.0 * B * 64 ** 3 * 16 * 4
-DOM_EXEC_BF16 = 6.0 * 2.0 * B * 64 ** 3 * 27 * 16 * 16 * (16.0 / 36.0) * ((64 + 1 - 4.0 / 3.0) / 64)      # bench.py wino_exec_factor(16, 64, 32) x six bf16 product terms
+DOM_EXEC_BF16 = 4.0 * 2.0 * B * 64 ** 3 * 27 * 16 * 16 * (16.0 / 36.0) * ((64 + 1 - 4.0 / 3.0) / 64)      # bench.py wino_exec_factor(16, 64, 32) x four fp16 product terms (two K = 32 MFMAs per row)
 trace_cmd = open(os.path.join(src, 'trace_cmd.txt')).read().strip() if os.path.exists(os.path.join(src, 'trace_cmd.txt')) else 'python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary'
 with open(os.path.join(dst, f'{tag}_bench_kernel_summary.md'), 'w') as f:
     f.write(f'# {tag}: `rocprofv3 --kernel-trace --stats -- {trace_cmd}`\n\n')
