@@ -274,6 +274,117 @@ def cpu_baseline(model, w, blocks_np, budget_s=12.0):
                        f'PyTorch-CPU oneDNN fp32 convs + C range coder, {el:.1f} s')
 
 
+def standin_cloud():
+    """The synthetic stand-in for longdress_vox10_1300 the tests use (tests/test_codec_gpu.py): a thin shell at 1024^3, ~5e5 points,
+    ~190 occupied 64^3 blocks at octree level 4.  Seeded: the same cloud on every rank."""
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal((3_000_000, 3))
+    return np.unique(np.round(u / np.linalg.norm(u, axis=1, keepdims=True) * 200 + np.array([512, 500, 520])).astype(np.int64), axis=0).astype(np.float64)
+
+
+def run_configs2(args, dist, rank, world, device, ctx, coder_threads):
+    """BASELINE.json configs[2]: ONE octree-split cloud through compress_blocks / decompress_blocks (the calls of
+    /root/reference/src/compress_octree.py:97-105 and decompress_octree.py:60-66), its blocks sharded over the ranks (sharding.py), the
+    closing collectives INSIDE the clock.  Strong scaling: the cloud is fixed, `value` = blocks of the cloud x steps / max-over-ranks time.
+    A step = encode (partitioned blocks on the host -> container bytes on rank 0) + the hand-over of the container (rank 0 writes a file,
+    every rank reads it, as the two CLIs do) + decode (-> points on rank 0)."""
+    import gzip
+    import io
+    import tempfile
+    from pcc_geo_cnn_v2_amd import model_syntax, sharding
+    from pcc_geo_cnn_v2_amd.utils.octree_coding import partition_octree
+    R, level, res = 1024, 4, 64
+    longdress = os.environ.get('PCC_BENCH_CLOUD')           # a real vox10 .ply when present (no dataset ships with the container)
+    if longdress:
+        from pcc_geo_cnn_v2_amd.utils import pc_io
+        pts = pc_io.load_points([longdress])[0].astype(np.float64)
+    else:
+        pts = standin_cloud()
+    blocks, binstr = partition_octree(pts, [0, 0, 0], [R] * 3, level)
+    enc = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads)
+    enc.compress([1, 1, res, res, res])
+    w = synthetic_weights(enc)
+    enc.set_weights(w)
+    dec = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads)
+    dec.decompress()
+    dec.set_weights({k: v for k, v in enc.get_weights().items() if not k.startswith(('analysis/', 'hyper_analysis/'))})
+    path = os.path.join(tempfile.gettempdir(), f'pcc_bench_cfg2_{os.environ.get("MASTER_PORT", "0")}.bin')
+    phase = {'encode': 0.0, 'handover': 0.0, 'decode': 0.0}
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        t0 = time.perf_counter()
+        streams, infos, _ = enc.compress_blocks(ctx, blocks, binstr, pts, R, level, opt_metrics=('d1_mse',), fixed_threshold=args.fixed_threshold, need_points=False)
+        t1 = time.perf_counter()
+        if rank == 0:
+            raw = model_syntax.save_compressed_file(binstr, streams[0], R, level, strict=True)
+            with open(path + '.tmp', 'wb') as fh:
+                fh.write(gzip.compress(raw, 6))
+            os.replace(path + '.tmp', path)
+        if dist is not None:
+            dist.barrier()          # the decoder processes start after the encoder wrote the file
+        with gzip.open(path, 'rb') as fh:
+            _, _, binstr2, data2 = model_syntax.load_compressed_file(fh)
+        t2 = time.perf_counter()
+        out, _ = dec.decompress_blocks(ctx, data2, [res] * 3)
+        t3 = time.perf_counter()
+        phase['encode'] += t1 - t0; phase['handover'] += t2 - t1; phase['decode'] += t3 - t2
+        return (sum(len(b) for b in out) if out is not None else 0), os.path.getsize(path)
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    for k in phase:
+        phase[k] = 0.0
+    sharding.stats_begin()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_pts, n_bytes = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    coll = sharding.stats_end()
+    if dist is not None:
+        tt = torch.tensor([elapsed, coll['seconds']], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, coll_s = float(tt[0].item()), float(tt[1].item())
+    else:
+        coll_s = coll['seconds']
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+        out = {'metric': 'voxel_blocks_64cubed_per_sec_encode_decode_ONE_CLOUD_SHARDED_configs2_not_the_headline', 'value': len(blocks) * args.steps / elapsed, 'unit': 'blocks/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 2), 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+               'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': ('BASELINE.json configs[2]: c3p, one vox10-sized cloud octree-split (level 4) into 64^3 blocks, sharded over the ranks in contiguous '
+                                       'Morton ranges, ' + ('fixed threshold' if args.fixed_threshold else 'adaptive threshold search on d1_mse (the CLI default)') + ', compress_blocks + container hand-over + decompress_blocks; '
+                                       + ('cloud = ' + os.path.basename(longdress) if longdress else 'cloud = seeded thin-shell stand-in for longdress_vox10_1300 (no dataset in the container)')),
+                          'points': int(len(pts)), 'blocks': len(blocks), 'blocks_per_rank': sharding.shard_sizes(len(blocks), world), 'pipeline_chunk': args.chunk,
+                          'container_bytes_gzip': int(n_bytes), 'decoded_points': int(n_pts), 'codec_numerics': ctx.numerics_tag('fp32'),
+                          'phase_ms_per_step_rank0': {k: 1e3 * v / args.steps for k, v in phase.items()},
+                          'what_a_step_includes': 'host: dense-block upload, range coder, whole-cloud D1 metrics of the selected reconstruction (select_best_per_opt_metric: KD-trees '
+                                                  'on the host, the original cloud is replicated), container serialisation + gzip, file write / read; GPU: both graphs and the threshold search; '
+                                                  'collectives: sharding.py (2 per cloud on the encoder, 2 on the decoder)'},
+               'final_collectives_ms': 1e3 * coll_s / args.steps, 'final_collectives_calls_per_step': coll['calls'] / args.steps,
+               'final_collectives_bytes_sent_per_step_rank0': coll['bytes'] / args.steps,
+               'final_collectives_note': 'max over ranks of the host wall time inside the collectives of sharding.py (call -> result on the host), inside the clock; 0 at world 1',
+               'roofline': None, 'cpu_baseline': None}
+        if dist is not None:
+            out['multi_gpu'] = {'rccl_world_size': dist.get_world_size(), 'backend': dist.get_backend()}
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def self_launch(n):
     import socket
     import subprocess
@@ -331,9 +442,11 @@ def main():
                     help='host range-coder threads of this rank (default: logical cores / ranks); for studying the host share')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
                     help="fp32 = the reference's arithmetic (the headline number); fp16 = fp16 MFMA / fp32 accumulate (BASELINE.json configs[4] flavour, informational)")
-    ap.add_argument('--workload', default='configs1', choices=['configs1', 'configs4'],
+    ap.add_argument('--workload', default='configs1', choices=['configs1', 'configs4', 'configs2'],
                     help='configs1 = BASELINE.json configs[1] (c3p, batch 32, 64^3: the headline); configs4 = configs[4] (deepest config, '
-                         '128^3 blocks, batch 8, fp16 MFMA): a SEPARATE, labelled line, never the headline')
+                         '128^3 blocks, batch 8, fp16 MFMA): a SEPARATE, labelled line, never the headline; configs2 = configs[2] (one octree-split cloud '
+                         'sharded over the ranks, strong scaling, closing collectives inside the clock): also a separate, labelled line')
+    ap.add_argument('--fixed-threshold', action='store_true', help='configs2: --fixed_threshold of the CLI instead of the adaptive search')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / collective skeleton only (gloo on CPU, no GPU work, value is meaningless): used by the CPU tests')
     args = ap.parse_args()
@@ -376,6 +489,8 @@ def main():
     # cores this rank owns: 8 ranks in a 16-core container get 2 each)
     cores_per_rank = max(1, ops.usable_cores() // max(world, 1))
     coder_threads = args.coder_threads or cores_per_rank
+    if args.workload == 'configs2':
+        return run_configs2(args, dist, rank, world, device, ctx, coder_threads)
     model = ModelConfigType['c3p'].build(batch_size=args.chunk, coder_threads=coder_threads, precision=args.precision)
     model.compress([1, 1, RES, RES, RES])
     w = synthetic_weights(model)

@@ -131,11 +131,14 @@ def _write_rate_point(target, decoded_path, binstr, streams, info, args, blocks,
 
 
 def compress(args):
+    from .utils import cli_timing as T
+    T.mark('process_start_to_main')
     import torch
     from . import ops
     from .model_configs import ModelConfigType
     from .utils import pc_io
     from .utils.octree_coding import partition_octree
+    T.mark('imports')
 
     clouds, with_normals = _plan(args)
     if getattr(args, 'd2_search', None):
@@ -145,19 +148,26 @@ def compress(args):
     if args.debug and world > 1:
         raise AssertionError('--debug dumps every intermediate of every block: run it on one GPU')
     sess = ops.get_context(torch.device('cuda', local))        # what tf.Session is to the reference (compress_octree.py:84)
+    T.mark('context', sess.device)
 
     geometry = pc_io.load_points(args.input_files, batch_size=args.read_batch_size)
     if with_normals:
         geometry = [np.hstack((xyz, pc_io.load_normals(path))) for xyz, path in zip(geometry, args.input_normals)]
+    T.mark('ply_read')
     box, block_shape = _block_grid(args.resolution, args.octree_level, args.data_format)
     logger.info('Performing octree partitioning')
     partitions = [partition_octree(cloud, [0, 0, 0], box, args.octree_level) for cloud in geometry]
+    T.mark('partition')
     logger.info(f'Processing resolution {args.resolution} with octree level {args.octree_level} resulting in dense_tensor_shape '
                 f'{block_shape} and {sum(len(blocks) for blocks, _ in partitions)} blocks')
 
     model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size, precision=args.precision)
     model.compress(np.concatenate(((1,), block_shape)))
     model.restore(args.checkpoint_dir)      # asserts 'Checkpoint ... was not found' like compress_octree.py:91
+    T.mark('checkpoint_restore')
+    if T.enabled():      # the weight repack + upload happens on the first codec call: make it a phase of its own
+        model._codec(sess)
+        T.mark('weights_repack_upload', sess.device)
 
     want_points = clouds[0].decoded is not None or args.debug
     for cloud, points, (blocks, binstr) in zip(clouds, geometry, partitions):
@@ -165,6 +175,7 @@ def compress(args):
         streams, infos, debug_t_list = model.compress_blocks(
             sess, blocks, binstr, points, args.resolution, args.octree_level, with_normals=with_normals, opt_metrics=args.opt_metrics,
             max_deltas=args.max_deltas, fixed_threshold=args.fixed_threshold, debug=args.debug, need_points=want_points)
+        T.mark('compress_blocks', sess.device)
         if rank == 0:       # the other ranks only took part in the collectives
             if len(streams) != len(cloud.targets):
                 raise AssertionError(f'{len(streams)} rate points for {len(cloud.targets)} output files')
@@ -172,6 +183,8 @@ def compress(args):
                 infos[n]['numerics_tag'] = sess.numerics_tag(args.precision)
                 _write_rate_point(target, None if cloud.decoded is None else cloud.decoded[n], binstr, streams[n], infos[n], args, blocks, debug_t_list)
             logger.info(f'Finished {cloud.source} to {", ".join(cloud.targets)} with {len(blocks)} blocks')
+        T.mark('container_gzip_write')
+    T.dump()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -217,3 +230,10 @@ if __name__ == '__main__':
     from . import want_hw_queues
     want_hw_queues()        # before torch (the HIP runtime) loads: compress() imports it
     compress(build_parser().parse_args())
+    # everything is written and closed: leave without the interpreter / runtime teardown (0.4 - 0.5 s of a 2 - 3 s process,
+    # profiles/r06_cli_wallclock.md); PCC_CLI_CLEAN_EXIT=1 keeps the ordinary exit
+    if not os.environ.get('PCC_CLI_CLEAN_EXIT'):
+        import sys
+        logging.shutdown()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)

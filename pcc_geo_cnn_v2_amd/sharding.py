@@ -28,6 +28,39 @@ import numpy as np
 import torch
 
 
+# Optional accounting of the collectives (bench.py --workload configs2): STATS = {'calls', 'seconds', 'bytes'} while enabled.  `seconds` is
+# host wall time from the call to the result on the host (the codec paths consume every collective on the host), `bytes` what this rank sent.
+STATS = None
+
+
+def stats_begin():
+    global STATS
+    STATS = {'calls': 0, 'seconds': 0.0, 'bytes': 0}
+
+
+def stats_end():
+    global STATS
+    out, STATS = STATS, None
+    return out
+
+
+class _Timed:
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+
+    def __enter__(self):
+        if STATS is not None:
+            import time
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if STATS is not None:
+            import time
+            STATS['calls'] += 1
+            STATS['seconds'] += time.perf_counter() - self.t0
+            STATS['bytes'] += self.nbytes
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced range [lo, hi) of rank `rank` (the first n % world ranks get one more)."""
     q, r = divmod(n_items, world)
@@ -83,9 +116,10 @@ def all_gather_rows(rows, device=None, counts=None):
     world, dev = d.get_world_size(), _device(d, device)
     cnt = _row_counts(d, rows.shape[0], counts, dev)
     pad = _padded(rows, cnt, dev)
-    bufs = [torch.zeros_like(pad) for _ in range(world)]
-    d.all_gather(bufs, pad)
-    return np.concatenate([bufs[r][:cnt[r]].cpu().numpy() for r in range(world)], 0)
+    with _Timed(pad.numel() * pad.element_size()):
+        bufs = [torch.zeros_like(pad) for _ in range(world)]
+        d.all_gather(bufs, pad)
+        return np.concatenate([bufs[r][:cnt[r]].cpu().numpy() for r in range(world)], 0)
 
 
 def gather_rows(rows, device=None, dst=0, counts=None):
@@ -97,11 +131,12 @@ def gather_rows(rows, device=None, dst=0, counts=None):
     world, rank, dev = d.get_world_size(), d.get_rank(), _device(d, device)
     cnt = _row_counts(d, rows.shape[0], counts, dev)
     pad = _padded(rows, cnt, dev)
-    bufs = [torch.zeros_like(pad) for _ in range(world)] if rank == dst else None
-    d.gather(pad, bufs, dst=dst)
-    if rank != dst:
-        return None
-    return np.concatenate([bufs[r][:cnt[r]].cpu().numpy() for r in range(world)], 0)
+    with _Timed(pad.numel() * pad.element_size()):
+        bufs = [torch.zeros_like(pad) for _ in range(world)] if rank == dst else None
+        d.gather(pad, bufs, dst=dst)
+        if rank != dst:
+            return None
+        return np.concatenate([bufs[r][:cnt[r]].cpu().numpy() for r in range(world)], 0)
 
 
 def gather_bytes(payload, device=None, dst=0, counts=None):
@@ -139,9 +174,10 @@ def all_reduce(arr, op, device=None):
     arr = np.ascontiguousarray(arr)
     if d is None:
         return arr
-    t = torch.from_numpy(arr.copy()).to(_device(d, device))
-    d.all_reduce(t, op=d.ReduceOp.MIN if op == 'min' else d.ReduceOp.SUM)
-    return t.cpu().numpy()
+    with _Timed(arr.nbytes):
+        t = torch.from_numpy(arr.copy()).to(_device(d, device))
+        d.all_reduce(t, op=d.ReduceOp.MIN if op == 'min' else d.ReduceOp.SUM)
+        return t.cpu().numpy()
 
 
 class RankGroup:
