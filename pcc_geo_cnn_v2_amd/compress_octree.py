@@ -119,7 +119,9 @@ def _write_rate_point(target, decoded_path, binstr, streams, info, args, blocks,
     payload = save_compressed_file(binstr, streams, args.resolution, args.octree_level, strict=True)
     write_tagged_gzip(target, payload, info['numerics_tag'])      # = gzip.open(target, 'wb').write(payload) + the tag in the member header
     with open(target + '.enc.metric.json', 'w') as fh:
-        json.dump({name: float(val) for name, val in info['metrics'].items()}, fh, sort_keys=True, indent=4)
+        # the reference's keys (floats) + the tag of the kernels that computed sigma-hat (a string: a tool that re-gzips the payload drops the
+        # header comment, this file keeps it; readers of the reference's JSON iterate over known metric names)
+        json.dump(dict({name: float(val) for name, val in info['metrics'].items()}, codec_numerics=info['numerics_tag']), fh, sort_keys=True, indent=4)
     if decoded_path is not None:
         pc_io.write_df(decoded_path, pc_io.pa_to_df(info['blocks_full']))
     if args.debug:
@@ -141,9 +143,6 @@ def compress(args):
     T.mark('imports')
 
     clouds, with_normals = _plan(args)
-    if getattr(args, 'd2_search', None):
-        from . import model_opt
-        model_opt.D2_SEARCH = args.d2_search
     rank, world, local = _join_process_group()
     if args.debug and world > 1:
         raise AssertionError('--debug dumps every intermediate of every block: run it on one GPU')
@@ -162,6 +161,7 @@ def compress(args):
                 f'{block_shape} and {sum(len(blocks) for blocks, _ in partitions)} blocks')
 
     model = ModelConfigType[args.model_config].build(data_format=args.data_format, batch_size=args.batch_size, precision=args.precision)
+    model.d2_search = getattr(args, 'd2_search', None)      # per model, not a module global
     model.compress(np.concatenate(((1,), block_shape)))
     model.restore(args.checkpoint_dir)      # asserts 'Checkpoint ... was not found' like compress_octree.py:91
     T.mark('checkpoint_restore')

@@ -246,7 +246,7 @@ D2_SEARCH = None      # 'kdtree' | 'gpu': set by the CLIs' --d2_search; None = t
 _d2_logged = False
 
 
-def d2_on_gpu():
+def d2_on_gpu(mode=None):
     """Where the d2_* statistics of the adaptive search come from.  DEFAULT (round 5): scipy KD-trees in the host worker pool
     -- the reference's own neighbour picks (pc_metric.py:114: among equidistant nearest neighbours it takes whatever the tree traversal
     returns), hence the reference's decisions (pinned by tests/golden/model_opt_d2.npz).  OPT-IN (--d2_search gpu / PCC_D2_GPU=1): the
@@ -256,9 +256,17 @@ def d2_on_gpu():
     evaluated with the reference's metric, drops by 0.2-1.2 dB -- the search then minimises a function other than the one it is judged by.
     d1_* metrics never depend on the pick and always come from the GPU."""
     global _d2_logged
-    mode = D2_SEARCH or ('kdtree' if os.environ.get('PCC_D2_HOST') is not None else 'gpu' if os.environ.get('PCC_D2_GPU') is not None else 'kdtree')
-    if mode == 'gpu' and not _d2_logged:
+    # precedence: the caller's model (`model.d2_search`, set by the CLI's --d2_search), the module default (tools, tests), the environment
+    if mode is None and D2_SEARCH is None and os.environ.get('PCC_D2_HOST') is not None and os.environ.get('PCC_D2_GPU') is not None:
+        logger.warning('PCC_D2_HOST and PCC_D2_GPU are both set: PCC_D2_HOST wins (kdtree)')
+    mode = mode or D2_SEARCH or ('kdtree' if os.environ.get('PCC_D2_HOST') is not None else 'gpu' if os.environ.get('PCC_D2_GPU') is not None else 'kdtree')
+    if not _d2_logged:
         _d2_logged = True
+        if mode != 'gpu':
+            logger.info('d2_* threshold search: statistics from scipy KD-trees in the host worker pool (the reference\'s neighbour picks; 8-18x slower per cloud than '
+                        '--d2_search gpu, whose decisions differ on most blocks of a voxelised surface: DESIGN.md 3.8)')
+    if mode == 'gpu' and _d2_logged != 'gpu':
+        _d2_logged = 'gpu'
         logger.warning('d2_* threshold search on the GPU (opt-in): equidistant nearest neighbours resolve to the lowest (x, y, z), not to '
                        'scipy\'s KD-tree pick as in the reference; decisions differ on most blocks of a voxelised surface (DESIGN.md 3.8)')
     return mode == 'gpu'

@@ -181,49 +181,53 @@ class ResidualLayer(Layer):
         return [c for layer in self._layers for c in layer.conv_layers()]
 
 
+# The conv stacks of /root/reference/src/model_transforms.py as DATA, one row per conv in Keras construction order:
+# (transposed, output channels ('F' = the constructor's `filters`), cubic kernel size (None = the constructor's), stride, use_bias, activated)
+_STACKS = {
+    'AnalysisTransformV1': [(0, 'F', 9, 2, 1, 1), (0, 'F', 5, 2, 1, 1), (0, 'F', 5, 2, 0, 0)],                 # :41-48
+    'SynthesisTransformV1': [(1, 'F', 5, 2, 1, 1), (1, 'F', 5, 2, 1, 1), (1, 1, 9, 2, 1, 1)],                   # :51-59 (final activation: ReLU)
+    'AnalysisBlock': [(0, 'F', None, 'S', 1, 1), (0, 'F', None, 1, 1, 1), (0, 'F', None, 1, 1, 1)],             # :62-70 ('S' = the block's strides)
+    'SynthesisBlock': [(1, 'F', None, 'S', 1, 1), (1, 'F', None, 1, 1, 1), (1, 'F', None, 1, 1, 1)],            # :73-81
+    'HyperAnalysisTransform': [(0, 'F', None, 1, 1, 1), (0, 'F', None, 2, 1, 1), (0, 'F', None, 1, 0, 0)],      # :140-147
+    'HyperSynthesisTransform': [(1, 'F', None, 1, 1, 1), (1, 'F', None, 2, 1, 1), (1, 'F', None, 1, 1, 1)],     # :150-158
+}
+
+
+def _stack(name, filters, data_format, activation, kernel_size=None, strides=None):
+    """The Conv3D / Conv3DTranspose objects of one row set of _STACKS."""
+    convs = []
+    for transposed, cout, k, stride, bias, act in _STACKS[name]:
+        ks = kernel_size if k is None else (k, k, k)
+        st = strides if stride == 'S' else (stride,) * 3
+        convs.append((Conv3DTranspose if transposed else Conv3D)(filters if cout == 'F' else cout, ks, strides=st, padding='same',
+                                                                 data_format=data_format, use_bias=bool(bias), activation=activation if act else None))
+    return convs
+
+
 class AnalysisTransformV1(SequentialLayer):
     NET_ID = L.PCC_NET_ANALYSIS_V1
 
     def __init__(self, filters, data_format=None, activation=relu, *args, **kwargs):
-        data_format = normalize_data_format(data_format)
-        params = {'strides': (2, 2, 2), 'padding': 'same', 'data_format': data_format, 'filters': filters}
-        layers = [Conv3D(kernel_size=(9, 9, 9), use_bias=True, activation=activation, **params),
-                  Conv3D(kernel_size=(5, 5, 5), use_bias=True, activation=activation, **params),
-                  Conv3D(kernel_size=(5, 5, 5), use_bias=False, activation=None, **params)]
-        super().__init__(layers, *args, **kwargs)
+        super().__init__(_stack('AnalysisTransformV1', filters, normalize_data_format(data_format), activation), *args, **kwargs)
 
 
 class SynthesisTransformV1(SequentialLayer):
     NET_ID = L.PCC_NET_SYNTHESIS_V1
 
     def __init__(self, filters, data_format=None, activation=relu, *args, **kwargs):
-        data_format = normalize_data_format(data_format)
-        params = {'strides': (2, 2, 2), 'padding': 'same', 'data_format': data_format, 'use_bias': True,
-                  'activation': activation}
-        layers = [Conv3DTranspose(filters, (5, 5, 5), **params),
-                  Conv3DTranspose(filters, (5, 5, 5), **params),
-                  Conv3DTranspose(1, (9, 9, 9), **params)]
-        super().__init__(layers, *args, **kwargs)
+        super().__init__(_stack('SynthesisTransformV1', filters, normalize_data_format(data_format), activation), *args, **kwargs)
 
 
 class AnalysisBlock(ResidualLayer):
-    def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), strides=(2, 2, 2), activation=relu,
-                 *args, **kwargs):
+    def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), strides=(2, 2, 2), activation=relu, *args, **kwargs):
         data_format = normalize_data_format(data_format)
-        params = {'padding': 'same', 'data_format': data_format, 'use_bias': True, 'activation': activation,
-                  'filters': filters, 'kernel_size': kernel_size}
-        layers = [Conv3D(strides=strides, **params), Conv3D(**params), Conv3D(**params)]
-        super().__init__(layers, *args, data_format=data_format, **kwargs)
+        super().__init__(_stack('AnalysisBlock', filters, data_format, activation, kernel_size, strides), *args, data_format=data_format, **kwargs)
 
 
 class SynthesisBlock(ResidualLayer):
-    def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), strides=(2, 2, 2), activation=relu,
-                 *args, **kwargs):
+    def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), strides=(2, 2, 2), activation=relu, *args, **kwargs):
         data_format = normalize_data_format(data_format)
-        params = {'padding': 'same', 'data_format': data_format, 'use_bias': True, 'activation': activation,
-                  'filters': filters, 'kernel_size': kernel_size}
-        layers = [Conv3DTranspose(strides=strides, **params), Conv3DTranspose(**params), Conv3DTranspose(**params)]
-        super().__init__(layers, *args, data_format=data_format, **kwargs)
+        super().__init__(_stack('SynthesisBlock', filters, data_format, activation, kernel_size, strides), *args, data_format=data_format, **kwargs)
 
 
 def _v2(block, first, out_layer, fs, data_format, kernel_size, activation, residual_mode):
@@ -282,23 +286,14 @@ class HyperAnalysisTransform(SequentialLayer):
     NET_ID = L.PCC_NET_HYPER_ANALYSIS
 
     def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), activation=relu, *args, **kwargs):
-        data_format = normalize_data_format(data_format)
-        params = {'padding': 'same', 'data_format': data_format, 'filters': filters, 'kernel_size': kernel_size}
-        layers = [Conv3D(use_bias=True, activation=activation, **params),
-                  Conv3D(use_bias=True, activation=activation, strides=(2, 2, 2), **params),
-                  Conv3D(use_bias=False, activation=None, **params)]
-        super().__init__(layers, *args, **kwargs)
+        super().__init__(_stack('HyperAnalysisTransform', filters, normalize_data_format(data_format), activation, kernel_size), *args, **kwargs)
 
 
 class HyperSynthesisTransform(SequentialLayer):
     NET_ID = L.PCC_NET_HYPER_SYNTHESIS
 
     def __init__(self, filters, data_format=None, kernel_size=(3, 3, 3), activation=relu, *args, **kwargs):
-        data_format = normalize_data_format(data_format)
-        params = {'padding': 'same', 'data_format': data_format, 'activation': activation, 'use_bias': True,
-                  'filters': filters, 'kernel_size': kernel_size}
-        layers = [Conv3DTranspose(**params), Conv3DTranspose(strides=(2, 2, 2), **params), Conv3DTranspose(**params)]
-        super().__init__(layers, *args, **kwargs)
+        super().__init__(_stack('HyperSynthesisTransform', filters, normalize_data_format(data_format), activation, kernel_size), *args, **kwargs)
 
 
 class TransformType(Enum):

@@ -512,7 +512,7 @@ class CompressionModel:
                 # table) a few chunks later, so the pool always holds several chunks' worth of blocks.
                 want_d2 = any(m.startswith('d2_') for m in opt_metrics)
                 on_gpu = gpu_search_supported(opt_metrics, dhw)
-                gpu_d2 = want_d2 and on_gpu and d2_on_gpu()          # round 4: nearest-index transforms, stated tie rule
+                gpu_d2 = want_d2 and on_gpu and d2_on_gpu(getattr(self, 'd2_search', None))          # nearest-index transforms, stated tie rule: opt-in
                 strings = enc['finish']()
                 item = dict(chunk=chunk, x_hat=x_hat, futures=None, d1=None, gpu_d2=gpu_d2)
                 if (want_d2 and not gpu_d2) or not on_gpu:
@@ -709,33 +709,51 @@ class CompressionModel:
         q_a, k = [], 0
         threaded = None
         trace = os.environ.get('PCC_STAGE_TIMES')          # host time per pipeline stage and iteration (ms), to stderr
-        for x in dense_chunks:
-            B, dhw = x.shape[0], tuple(x.shape[1:4])
-            if threaded is None:
-                threaded = (2 * B <= _usable_cores() or bool(os.environ.get('PCC_FORCE_HELPER_THREADS'))) and not os.environ.get('PCC_NO_HELPER_THREADS')
-            t0 = time.perf_counter()
-            enc = self._encode_batch(ctx, x, False, thr=self._thr_tensor(ctx, [thr_idx] * B), slot=k % 3)
-            # (only when both coders fit the usable cores side by side: with 32 streams per call on a 16-core container the two
-            # would just take turns, with scheduler jitter on top -- measured: 7-12 ms hiccups in the 64^3 headline)
-            enc['strings'] = self._coder_thread().submit(enc['finish']) if 2 * B <= _usable_cores() else _Immediate(enc['finish'])
-            k += 1
-            q_a.append((enc, dhw, B))
-            t1 = time.perf_counter()
-            if len(q_a) > 1:
+        try:
+            for x in dense_chunks:
+                B, dhw = x.shape[0], tuple(x.shape[1:4])
+                if threaded is None:
+                    threaded = (2 * B <= _usable_cores() or bool(os.environ.get('PCC_FORCE_HELPER_THREADS'))) and not os.environ.get('PCC_NO_HELPER_THREADS')
+                t0 = time.perf_counter()
+                enc = self._encode_batch(ctx, x, False, thr=self._thr_tensor(ctx, [thr_idx] * B), slot=k % 3)
+                # (only when both coders fit the usable cores side by side: with 32 streams per call on a 16-core container the two
+                # would just take turns, with scheduler jitter on top -- measured: 7-12 ms hiccups in the 64^3 headline)
+                enc['strings'] = self._coder_thread().submit(enc['finish']) if 2 * B <= _usable_cores() else _Immediate(enc['finish'])
+                k += 1
+                q_a.append((enc, dhw, B))
+                t1 = time.perf_counter()
+                if len(q_a) > 1:
+                    stage_a(q_a.pop(0))
+                t2 = time.perf_counter()
+                if len(q_g) > 1:
+                    out = stage_g(q_g.pop(0))
+                    if trace:
+                        print(f'stage ms: enqueue {1e3 * (t1 - t0):.2f} decode+enqueue {1e3 * (t2 - t1):.2f} gather {1e3 * (time.perf_counter() - t2):.2f}',
+                              file=sys.stderr)
+                    yield out
+            while q_a:
                 stage_a(q_a.pop(0))
-            t2 = time.perf_counter()
-            if len(q_g) > 1:
-                out = stage_g(q_g.pop(0))
-                if trace:
-                    print(f'stage ms: enqueue {1e3 * (t1 - t0):.2f} decode+enqueue {1e3 * (t2 - t1):.2f} gather {1e3 * (time.perf_counter() - t2):.2f}',
-                          file=sys.stderr)
-                yield out
-        while q_a:
-            stage_a(q_a.pop(0))
-        while q_b:
-            q_g.append(stage_b(q_b.pop(0)))
-        while q_g:
-            yield stage_g(q_g.pop(0))
+            while q_b:
+                q_g.append(stage_b(q_b.pop(0)))
+            while q_g:
+                yield stage_g(q_g.pop(0))
+        finally:
+            # an abandoned generator (or a stage that raised) must not leave helper-thread jobs running against buffers the caller is
+            # about to free: wait for whatever is still queued
+            for enc_, _, _ in q_a:
+                fut = enc_.get('strings')
+                if hasattr(fut, 'cancel') and not fut.cancel():
+                    try:
+                        fut.result()
+                    except Exception:
+                        pass
+            for item in list(q_b) + list(q_g):
+                for fut in (item if isinstance(item, tuple) else (item,)):
+                    if hasattr(fut, 'cancel') and hasattr(fut, 'result') and not fut.cancel():
+                        try:
+                            fut.result()
+                        except Exception:
+                            pass
 
     def decompress_blocks(self, sess, blocks, x_shape, debug=False):
         """Uses the decompression model to decompress a point cloud (model_types.py:220-238).
@@ -1048,7 +1066,7 @@ class CompressionModelV2(CompressionModel):
             idx_h.copy_(idx_s, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(side)
-        return dict(strings=strings, idx_h=idx_h, ev=ev, z_hat=z_hat, sigma=sigma, idx=idx, zsym_h=zsym_h)
+        return dict(strings=strings, idx_h=idx_h, ev=ev, z_hat=z_hat, sigma=sigma, idx=idx, zsym_h=zsym_h, device=ctx.device)
 
     def _decode_phase_b_host(self, st):
         """The host part of phase b: wait for the CDF-row indexes, range-decode the y strings into a pinned buffer.  No GPU work is
@@ -1057,6 +1075,10 @@ class CompressionModelV2(CompressionModel):
         gc = self.conditional_bottleneck
         strings, idx_h = st['strings'], st['idx_h']
         B = len(strings)
+        # may run on the 'ydec' helper thread: pinned allocations below must be made with THIS model's device current (a helper thread
+        # starts on device 0 and would touch or create a context there on a rank that owns another GPU)
+        if st.get('device') is not None:
+            torch.cuda.set_device(st['device'])
         st['ev'].synchronize()
         ysym_h, ysym_release = self._pinned.ring('dec_ysym', idx_h.shape, _host_dtypes()[0])
         n = int(np.prod(idx_h.shape[1:]))

@@ -53,8 +53,11 @@ class Context:
         return int(fam.value), int(sw.value)
 
     def numerics_tag(self, precision='fp32'):
-        """What the CLIs record beside a stream (gzip header comment, .enc.metric.json) and the decoder compares."""
+        """What the CLIs record beside a stream (gzip header comment and `.enc.metric.json` key `codec_numerics`) and the decoder compares.
+        Switches that are documented AND tested as bit-identical (P16, COUT1_T16: launch geometry only) are masked out: they must not
+        make a decoder refuse a stream."""
         fam, sw = self.numerics()
+        sw &= ~(L.PCC_NUM['p16'] | L.PCC_NUM['cout1_t16'])
         return f'pcc_geo_cnn_v2_amd/k{fam}/sw{sw:04x}/{precision}'
 
     def set_numerics(self, **switches):

@@ -122,6 +122,10 @@ def round3(model_opt, pc_metric, octree_coding):
     d2['n_cases'] = np.array([n_cases])
     d2['opt_metrics'], d2['max_deltas'] = np.array(mets), np.array(deltas)
     np.savez_compressed(os.path.join(OUT, 'model_opt_d2.npz'), **d2)
+    import json, scipy
+    json.dump({'scipy_version_the_fixtures_embody': scipy.__version__, 'reference_pins': 'scipy~=1.4.1 (requirements.txt:10)',
+               'note': 'the d2_* decisions in model_opt_d2*.npz carry the KD-tree neighbour picks of this scipy (src/utils/pc_metric.py:114: implementation-dependent)'},
+              open(os.path.join(OUT, 'model_opt_d2.meta.json'), 'w'), indent=1)
 
     # ---- select_best_per_opt_metric (model_types.py:128-176)
     _tf_import_shims()
