@@ -39,7 +39,7 @@ FLOPS_PER_BLOCK = 31.086e9   # c3p @64^3, compress 16.562 + deco
 PEAK_FP32_MFMA = 157.3       # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 PEAK_BF16_MFMA = 2500.0      # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_16x16x32_bf16)
 PEAK_HBM = 8000.0            # GB/s
-# tools/host_budget.sh: cores per rank below which the 1-GPU rate drops by more than 3 %
+# tools/host_budget.sh (DESIGN_HISTORY.md section 6): cores per rank below which the 1-GPU rate drops by more than 3 %
 HOST_MIN_CORES_PER_RANK = 3        # late round 4 (4.2 - 4.5 ms steps): 16: 7567 / 7100, 4: 7486 / 7049, 3: 7438 / 7078, 2: 7163 / 6998 blocks/s (profiles/r04_host_budget.log)
 # Synthetic weights (no trained checkpoints exist in the container): Glorot-uniform kernels scaled so that the
 # coded statistics resemble a trained codec at a high-rate point: ~4 % non-zero y symbols (~1.5-2 KB per
@@ -702,7 +702,7 @@ def main():
                             'accumulate), error equal to the exact-fp32 MFMA kernel (tests/test_conv_gpu.py).  The matrix work is 2.7x shorter than on the fp32 '
                             'pipe, so the launch is no longer MFMA-bound: the nearest hardware roof is HBM (achieved/frac = algorithmic bytes: input + residual '
                             '+ output, / HIP-event launch time / 8 TB/s); what actually limits it is VALU issue of the operand split at one wave per SIMD '
-                            '(DESIGN.md 3.0c, profiles/r04_*).  `mfma` restates it against the matrix peaks; PCC_NO_SPLIT=1 gives the fp32 line')
+                            '(DESIGN_HISTORY.md 3.0c, profiles/r04_*).  `mfma` restates it against the matrix peaks; PCC_NO_SPLIT=1 gives the fp32 line')
             else:
                 dom_kernel = 'conv16_wino_kernel<relu> (Conv3DTranspose 16->16 k3 s1 @64^3 + residual: synthesis layer 8, timed in the encoder and in the decoder; layer 7 runs the same kernel: 4 launches per step)'
                 dom_note = ('achieved/frac = fp32 MFMA flops the kernel EXECUTES (Winograd F(2x2,3x3) in x-y + direct z: 16/36 * 63.67/64 of '

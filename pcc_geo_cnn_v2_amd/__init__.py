@@ -6,7 +6,7 @@ compress_octree.py / decompress_octree.py CLIs and the .ply.bin container)."""
 
 def want_hw_queues(n=8):
     """Four HIP streams carry the codec (kernels and three kinds of copies); the runtime's default of 4 hardware queues makes them
-    share a queue as soon as another library (RCCL) opens streams of its own.  GPU_MAX_HW_QUEUES only takes
+    share a queue as soon as another library (RCCL) opens streams of its own (DESIGN_HISTORY.md section 6).  GPU_MAX_HW_QUEUES only takes
     effect when it is set before the HIP runtime loads, i.e. before `import torch`: the entry points (bench.py, the CLIs) call this
     first thing; importing the package no longer changes the host process' environment.  Returns False (and logs) when HIP is
     already loaded, i.e. when the call came too late to matter."""

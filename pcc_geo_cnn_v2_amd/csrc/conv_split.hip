@@ -797,14 +797,14 @@ bool pcc_split_covers(const pcc_conv_desc* d) {
 // Measured (batch 32, tools/bench_one.py): 64 -> 64 @16^3 128 us against 138 - 146 us for conv16_wino_cin_kernel<4> and 234 us for the
 // exact-fp32 direct kernel; 32 -> 32 @32^3 333 us against 241 us (Winograd) and 468 us (fp32 direct): with R x CTW = 4 x 1 MFMA
 // groups per operand fetch the 32-channel launch is bound by its operand traffic (5 GB of weight fragments from L2, 15 GB of input
-// fragments from LDS per launch -- MFMA busy 0.29 - 0.46), so the Winograd kernel keeps those layers.
+// fragments from LDS per launch -- MFMA busy 0.29 - 0.46), so the Winograd kernel keeps those layers (DESIGN_HISTORY.md 3.0d).
 // The choice depends on the layer shape ONLY, never on the batch: encoder and decoder run with different batch sizes and must produce
 // the same bits (tests/test_codec_gpu.py::test_blocks_128_cubed_roundtrip_and_layer_parity caught a batch-dependent rule).
 bool pcc_split_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     (void)ctx;
     // 64 channels: 128 us against 138 - 146 (Winograd fp32) @16^3 x 32.  32 channels: only on the small grids (38.5 against 45 us @16^3;
     // at 32^3 the Winograd kernel's 241 us stand against 332: every tile of this kernel pays its staging, split and epilogue
-    // un-overlapped -- at bf16 MFMA rates they are as long as the 27 taps themselves)
+    // un-overlapped -- at bf16 MFMA rates they are as long as the 27 taps themselves, see DESIGN_HISTORY.md 3.0d)
     return d->Cin == 64 || (d->Cin == 32 && d->D <= 16 && (d->W % 32 == 0 || d->W == 16));
 }
 

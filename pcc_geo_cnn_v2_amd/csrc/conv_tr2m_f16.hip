@@ -15,7 +15,7 @@
 //   * the fp16 weights of the cout tile (27 fragments of 1 KB per 32-channel cin group) are converted from the tr2g-order fp32 image in
 //     the prologue and stay LDS-resident; a 4-deep fragment ring (a tap is 4 MFMAs = 64 cycles) covers the LDS latency;
 //   * parity decomposition, three accumulator sets (192 AccVGPRs), the finished planes leaving under the first taps of the next plane,
-//     compile-time plane parity: conv_tr2m_kernel's.  The epilogue rounds to fp16 and stores 8 bytes per lane.
+//     compile-time plane parity: conv_tr2m_kernel's (DESIGN_HISTORY.md 3.3b).  The epilogue rounds to fp16 and stores 8 bytes per lane.
 // Summation order per output element: cin group of 32 -> tap -> the K = 32 chain of the instruction, fp32 accumulation, fixed:
 // bit-deterministic, independent of batch and z split; NOT the order of conv_tr2g_kernel<F16>, so the dispatch is a function of the layer
 // shape only (encoder and decoder must produce the same bits).

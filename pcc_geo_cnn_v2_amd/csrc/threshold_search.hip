@@ -248,7 +248,7 @@ PCC_API int pcc_d1_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, 
 // the rule on a voxel grid and the reference's own numbers depend on the pick of scipy's KD-tree (pc_metric.py:114), so the rule
 // here is stated and deterministic: among equidistant candidates the one with the LOWEST (x, y, z) in lexicographic order (= the
 // lowest row-major voxel index, the order of np.argwhere).  Per pass of the separable transform that is "smaller coordinate
-// wins a tie", which composes to the lexicographic rule.
+// wins a tie", which composes to the lexicographic rule (DESIGN_HISTORY.md 3.8).
 //   B -> A (once per block): full-grid index transform of A -> a*(v); e(v) = ((v - a*) . n[a*])^2 in fp64;
 //        D2_BA(t) = sum_{v : level(v) > t} e(v), one workgroup per (block, t), fixed summation order.
 //   A -> B (per threshold):  z and y passes on the grid, x pass at the points of A -> b*(a, t);  the decoded point b* gets the MEAN

@@ -252,7 +252,7 @@ def d2_on_gpu(mode=None):
     returns), hence the reference's decisions (pinned by tests/golden/model_opt_d2.npz).  OPT-IN (--d2_search gpu / PCC_D2_GPU=1): the
     nearest-index transforms of csrc/threshold_search.hip, 8-18x faster per cloud, ties to the lowest (x, y, z).  The two agree exactly
     where no tie occurs (tests/golden/model_opt_d2_tiefree.npz); on voxelised surfaces ties are the rule: measured (tools/d2_tie_table.py,
-    DESIGN.md 3.8) the d2_mse decision differs on 82-89 % of the blocks of a 1024^3 cloud and the D2 PSNR of the d2-optimised stream,
+    DESIGN_HISTORY.md 3.8) the d2_mse decision differs on 82-89 % of the blocks of a 1024^3 cloud and the D2 PSNR of the d2-optimised stream,
     evaluated with the reference's metric, drops by 0.2-1.2 dB -- the search then minimises a function other than the one it is judged by.
     d1_* metrics never depend on the pick and always come from the GPU."""
     global _d2_logged
@@ -264,11 +264,11 @@ def d2_on_gpu(mode=None):
         _d2_logged = True
         if mode != 'gpu':
             logger.info('d2_* threshold search: statistics from scipy KD-trees in the host worker pool (the reference\'s neighbour picks; 8-18x slower per cloud than '
-                        '--d2_search gpu, whose decisions differ on most blocks of a voxelised surface: DESIGN.md 3.8)')
+                        '--d2_search gpu, whose decisions differ on most blocks of a voxelised surface: DESIGN_HISTORY.md 3.8)')
     if mode == 'gpu' and _d2_logged != 'gpu':
         _d2_logged = 'gpu'
         logger.warning('d2_* threshold search on the GPU (opt-in): equidistant nearest neighbours resolve to the lowest (x, y, z), not to '
-                       'scipy\'s KD-tree pick as in the reference; decisions differ on most blocks of a voxelised surface (DESIGN.md 3.8)')
+                       'scipy\'s KD-tree pick as in the reference; decisions differ on most blocks of a voxelised surface (DESIGN_HISTORY.md 3.8)')
     return mode == 'gpu'
 
 

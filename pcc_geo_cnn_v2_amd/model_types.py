@@ -512,7 +512,7 @@ class CompressionModel:
                 # table) a few chunks later, so the pool always holds several chunks' worth of blocks.
                 want_d2 = any(m.startswith('d2_') for m in opt_metrics)
                 on_gpu = gpu_search_supported(opt_metrics, dhw)
-                gpu_d2 = want_d2 and on_gpu and d2_on_gpu(getattr(self, 'd2_search', None))          # nearest-index transforms, stated tie rule: opt-in
+                gpu_d2 = want_d2 and on_gpu and d2_on_gpu(getattr(self, 'd2_search', None))          # nearest-index transforms, stated tie rule: opt-in (DESIGN_HISTORY.md 3.8)
                 strings = enc['finish']()
                 item = dict(chunk=chunk, x_hat=x_hat, futures=None, d1=None, gpu_d2=gpu_d2)
                 if (want_d2 and not gpu_d2) or not on_gpu:

@@ -277,7 +277,7 @@ def test_usable_cores_respects_affinity_and_quota(monkeypatch, tmp_path):
 
 
 def test_entry_points_ask_for_eight_hardware_queues_and_the_import_leaves_the_environment_alone():
-    """The copy streams need hardware queues of their own beside RCCL's streams.  Importing the package
+    """The copy streams need hardware queues of their own beside RCCL's streams (DESIGN_HISTORY.md section 6).  Importing the package
     does not touch the host process' environment; the entry points call want_hw_queues() before torch loads, which
     respects a value the caller set and reports when it comes too late."""
     import os

@@ -70,7 +70,7 @@ def test_two_rank_sharded_compress_equals_single_process(tmp_path):
                     assert ma[k] == v, k
                 else:   # D2 depends on which of several equidistant neighbours is taken (cross-shard ties: lowest rank)
                     assert np.isclose(ma[k], v, rtol=0.05), (k, ma[k], v)
-    # the number of collectives DESIGN.md §6 states: no size exchanges (shard sizes are a function of (n_blocks, world))
+    # the number of collectives DESIGN_HISTORY.md §6 states: no size exchanges (shard sizes are a function of (n_blocks, world))
     for r in range(2):
         # round 5: TWO collectives per cloud, whatever the number of candidates (SURVEY.md 8e's "single gather" +
         # the strings): the MIN keys ride in the row all_gather, the partial tallies with the strings; when the keys are too many to move

@@ -162,7 +162,7 @@ def test_d2_search_against_the_reference_fixtures_and_tie_free_cases(ctx, oracle
             if mine != theirs:
                 differing.append((i, names[k], theirs, mine))
     # not "may differ where tied" but WHICH decisions the lowest-(x,y,z) rule moves on these fixtures (reference
-    # index -> GPU index; tools/d2_tie_table.py prints the table of DESIGN.md 3.8) -- a regression cannot hide behind `not all(free)`
+    # index -> GPU index; tools/d2_tie_table.py prints the table of DESIGN_HISTORY.md 3.8) -- a regression cannot hide behind `not all(free)`
     assert differing == [(0, 'd2_mse_inf', 198, 218), (0, 'd2_sum_max_inf', 198, 217), (0, 'd2_mse_2.0', 198, 218), (0, 'd2_sum_max_2.0', 198, 217),
                          (2, 'd2_sum_max_inf', 233, 232), (2, 'd2_sum_max_2.0', 233, 232)], differing
     # (b) tie-free cases: a handful of scattered points against a handful of scattered decoded voxels

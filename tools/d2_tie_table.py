@@ -7,7 +7,7 @@ reference's picks (scipy KD-tree traversal, /root/reference/src/utils/pc_metric.
  (2) two 1024^3 level-4 clouds through compress_blocks with ['d1_mse', 'd2_mse'] and normals under both searches: blocks whose d2
      decision differs, and the D1 / D2 PSNR of the decoded cloud each search ends up with (the stream length does not depend on the
      threshold index: one byte per block either way).
- Prints markdown; the counts are asserted by tests/test_threshold_search_gpu.py."""
+ Prints markdown (DESIGN_HISTORY.md 3.8); the counts are asserted by tests/test_threshold_search_gpu.py."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: blocks/s of the 1-GPU bench against the host cores one rank may use (taskset), and 4 ranks of 4 cores sharing the GPU --
-# the host budget an 8-rank node has to provide (table in DESIGN.md section 6).   tools/host_budget.sh [steps]
+# the host budget an 8-rank node has to provide (table in DESIGN_HISTORY.md section 6).   tools/host_budget.sh [steps]
 STEPS=${1:-100}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
