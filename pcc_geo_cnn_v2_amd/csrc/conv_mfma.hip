@@ -1730,7 +1730,7 @@ PCC_API int pcc_conv_mfma_supported(const pcc_conv_desc* d) {
 static bool tr2_has_split_image(int Cin, int Cout) { return (Cin == 32 && Cout == 16) || (Cin == 64 && (Cout == 32 || Cout == 64)); }
 
 // two-piece fp16 image of U behind everything else of a k3 stride-1 layer (conv_wino_f16s.hip): the 16- and 32-channel layers carry one
-static size_t wino_f16s_floats(int C) { return C <= 32 ? (size_t)NGROUPS(C) * NGROUPS(C) * PCC_WINO_UH_FLOATS + PCC_WINO_UH_TAIL : 0; }
+static size_t wino_f16s_floats(int C) { return (size_t)NGROUPS(C) * NGROUPS(C) * PCC_WINO_UH_FLOATS + PCC_WINO_UH_TAIL; }
 static size_t wino_f16s_offset(int C) {
     return (size_t)27 * C * C + (size_t)NGROUPS(C) * NGROUPS(C) * (PCC_WINO_U_FLOATS + PCC_WINO_UB_FLOATS) + pcc_f16_packed_bytes(C) / 4 +
            (C >= 32 ? pcc_split_packed_floats(C) : 0);
@@ -1874,16 +1874,23 @@ int pcc_conv3d_mfma(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const
 // The dispatch rules of the k3 stride-1 layers with Cin = Cout in {16, 32, 64} (shape + context state only), in the order
 // pcc_conv3d_mfma_thr applies them: 0 = a direct kernel, 1 = the direct split-bf16 kernel (conv_split.hip), 2 = Winograd exact fp32,
 // 3 = Winograd split-bf16 (16 channels), 4 = Winograd two-piece fp16 (16 / 32 channels, conv_wino_f16s.hip)
+static bool f16s64_preferred(const pcc_ctx* ctx, const pcc_conv_desc* d) {
+    return !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16 | PCC_CONV_CLIP01)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_F16S | PCC_NUM_NO_WINOGRAD | PCC_NUM_NO_WINOGRAD64) &&
+           pcc_wino_eligible(d) && pcc_wino_f16s_covers(d);
+}
 static int k3s1_route(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     const int ci = d->Cin;
     if (d->impl == PCC_IMPL_SPLIT) return 1;
+    // 64 channels on grids of 16-multiples: the two-piece fp16 Winograd kernel as two launches of two cin groups (conv_wino_f16s.hip)
+    // ahead of the direct bf16 kernel; PCC_NO_F16S=1 / PCC_NO_WINOGRAD64=1: the direct kernel (A/B)
+    if (d->impl == PCC_IMPL_AUTO && ci == 64 && f16s64_preferred(ctx, d)) return 4;
     if (d->impl == PCC_IMPL_AUTO && ci >= 32 && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_DIRECT) &&
         pcc_split_covers(d) && pcc_split_preferred(ctx, d))
         return 1;
     const bool no_wino = ctx->num(PCC_NUM_NO_WINOGRAD), no_wino32 = ctx->num(PCC_NUM_NO_WINOGRAD32), wino64 = !ctx->num(PCC_NUM_NO_WINOGRAD64);
     const bool want = d->impl == PCC_IMPL_WINOGRAD || (d->impl == PCC_IMPL_AUTO && !(d->flags & PCC_CONV_F16) && !no_wino && !(ci == 32 && (no_wino32 || d->D < 16)) && !(ci == 64 && !wino64));
     if (!(want && pcc_wino_eligible(d))) return 0;
-    if (!ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_F16S) && pcc_wino_f16s_covers(d) && (ci == 16 || !(d->flags & PCC_CONV_CLIP01))) return 4;
+    if (!ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_F16S) && pcc_wino_f16s_covers(d) && (ci == 16 || !(d->flags & PCC_CONV_CLIP01)) && !(ci == 64 && (d->flags & PCC_CONV_F16))) return 4;
     if (!ctx->num(PCC_NUM_NO_SPLIT) && pcc_wino_bf16_covers(d)) return 3;
     return 2;
 }

@@ -180,7 +180,9 @@ __device__ __forceinline__ unsigned f16s_scale_bits(unsigned m, int lsu) {
 // transformed and split into the same registers behind their last use, and tile m + 2 arrives global -> LDS.  The three output planes
 // in flight (192 AccVGPRs, ONE cout group per workgroup) stay live across the cin groups; only the last group of a plane reduces and
 // stores the finished output plane.  Ring slot of tile m = m mod 3 = (G (s mod 3) + c) mod 3: compile time, like the accumulator phase.
-template <bool RELU, bool CLIP, int G>
+// PRE (64-channel layers, second launch): `out` already holds the partial sums of the cin groups a first launch of this kernel
+// marched (flags cleared: raw A^T sums, un-scaled); they are added before the ReLU, in that fixed order.
+template <bool RELU, bool CLIP, int G, bool PRE = false>
 __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int nwg) {
     static_assert(G == 1 || G == 2, "one or two 16-channel cin groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -203,8 +205,9 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
 
     // ---- U -> LDS: the G images of this cout group ([cout group][cin group][lane][776 B], contiguous) straight global -> LDS
     {
+        // a.ncig = cin groups of the LAYER (the image holds [cout group][all cin groups]), a.ig0 = the first one this launch marches
         constexpr int UBYTES = G * UG_BYTES, NCH = (UBYTES + 1023) / 1024;
-        const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u + (size_t)cog * (UBYTES / 4), (unsigned)UBYTES);      // beyond the image: zeros
+        const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u + ((size_t)cog * a.ncig + a.ig0) * (UG_BYTES / 4), (unsigned)UBYTES);      // beyond the image: zeros
 #pragma unroll
         for (int k = 0; k < (NCH + 3) / 4; ++k) {
             const int chunk = k * 4 + wave;
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
     u32x4 A1[4], A2[4];         // U fragments of the row in flight: [Uh | Uh], [Ul | Ul] per point px
     f32x4 acc[3][16];           // three output planes in flight
     f32x4 S[2][2];
-    f32x4 resv[4], ost[4];
+    f32x4 resv[4], ost[4], prev[PRE ? 4 : 1];
     float mx = 0.f;             // max |stored value| of this lane (amax_out)
     // ---- pieces of the schedule.  V row r of a tile: Y = its fp32 values (yrow), H = cvt_pk(Y), L = fma_mix(Y - H).
     auto yrow = [&](auto r_tag) __attribute__((always_inline)) {
@@ -461,8 +464,14 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
 #pragma unroll
                 for (int v = 2 * oy; v < 2 * oy + 2; ++v) {
                     f32x4 o = S[v >> 1][v & 1];
-                    if (RELU) o = __builtin_elementwise_maximum(o, zero4);
-                    o = fma4s(o, inv2, resv[v]);     // zeros without PCC_CONV_ADD (zero-sized buffer)
+                    if constexpr (PRE) {
+                        o = fma4s(o, inv2, prev[v]);     // + the partial sums of the first launch, then ReLU, then the residual
+                        if (RELU) o = __builtin_elementwise_maximum(o, zero4);
+                        o = add4(o, resv[v]);
+                    } else {
+                        if (RELU) o = __builtin_elementwise_maximum(o, zero4);
+                        o = fma4s(o, inv2, resv[v]);     // zeros without PCC_CONV_ADD (zero-sized buffer)
+                    }
                     if (CLIP) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[c] = fminf(fmaxf(o[c], 0.f), 1.f);
@@ -475,7 +484,10 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
             }
             if constexpr (LAST && (q == 0 || q == 3) && !(PCC_WH_PROBE & 4)) {
 #pragma unroll
-                for (int v = 2 * (q / 3); v < 2 * (q / 3) + 2; ++v) resv[v] = buf_load4(rres, rvo0, rso[v]);
+                for (int v = 2 * (q / 3); v < 2 * (q / 3) + 2; ++v) {
+                    resv[v] = buf_load4(rres, rvo0, rso[v]);
+                    if constexpr (PRE) prev[v] = buf_load4(rout, ovo0, oso[v]);
+                }
             }
             // gfx950: a buffer_store_dwordx4 reads its data registers late (conv16_wino_kernel): keep them unwritten for one more slot
             if constexpr (LAST && q == 9) { asm volatile("" ::"v"(ost[0])); asm volatile("" ::"v"(ost[1])); }
@@ -485,7 +497,8 @@ __global__ void __launch_bounds__(NT, 1) conv16_wino_f16s_kernel(WinoArgs a, int
         // the LDS-direct loads of tile m+2 (F(3)) must have landed before the barrier publishes them; younger (last cin group only):
         // the residual loads of K(3) and the 4 stores of K(8) / K(11).  LDS reads stay in flight across the barrier.
         if (!FIN && !(PCC_WH_PROBE & 1)) {
-            if constexpr (LAST) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6) expcnt(7) lgkmcnt(15)
+            if constexpr (LAST && PRE) __builtin_amdgcn_s_waitcnt(0x0F78);       // vmcnt(8): + the two partial-sum loads of K(3)
+            else if constexpr (LAST) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6) expcnt(7) lgkmcnt(15)
             else __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
             __syncthreads();
         }
@@ -603,22 +616,25 @@ void pcc_wino_f16s_pack(int ngroups, const float* u_f32, float* out) {
     out[(size_t)ngroups * ngroups * PCC_WINO_UH_FLOATS] = su;
 }
 
-bool pcc_wino_f16s_covers(const pcc_conv_desc* d) { return (d->Cin == 16 && d->Cout == 16) || (d->Cin == 32 && d->Cout == 32); }
+bool pcc_wino_f16s_covers(const pcc_conv_desc* d) { return d->Cin == d->Cout && (d->Cin == 16 || d->Cin == 32 || d->Cin == 64); }
 
+// 64 channels: two launches of the two-group kernel (cin groups 0, 1 -> raw partial sums in `out`; groups 2, 3 add them before the
+// epilogue).  The partial sums of these layers are small (33 MB at 16^3 x 32): their read-modify-write costs nothing, and two resident U
+// images per workgroup is what LDS holds.  Both launches scale block n by the same s (the same input tensor's maximum).
 int pcc_conv_wino_f16s(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* uh_packed, const float* bias,
                        const float* residual, float* out, pcc_conv_ext* ext, hipStream_t st) {
     PCC_REQUIRE(pcc_wino_eligible(d) && pcc_wino_f16s_covers(d), "pcc_conv_wino_f16s: shape not covered");
-    const int G = d->Cin / 16;
-    PCC_REQUIRE(G == 1 || !(d->flags & PCC_CONV_CLIP01), "pcc_conv_wino_f16s: the 32-channel kernel does not clip");
+    const int NG = d->Cin / 16, G = NG >= 2 ? 2 : 1;
+    PCC_REQUIRE(NG == 1 || !(d->flags & PCC_CONV_CLIP01), "pcc_conv_wino_f16s: the multi-group kernels do not clip");
     WinoArgs a;
     a.in = in; a.bias = bias; a.res = residual; a.out = out;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
     a.nty = d->H / 16; a.ntx = d->W / 16;
     a.ocs = d->out_cstride ? d->out_cstride : d->Cout;
     a.oco = d->out_coffset;
-    a.nco = G; a.ics = d->Cin; a.rcs = d->Cout; a.ico = 0; a.ncig = G;
+    a.nco = NG; a.ics = d->Cin; a.rcs = d->Cout; a.ico = 0; a.ncig = NG; a.ig0 = 0;
     a.u = uh_packed; a.flags = d->flags;
-    a.utail = uh_packed + (size_t)G * G * PCC_WINO_UH_FLOATS;
+    a.utail = uh_packed + (size_t)NG * NG * PCC_WINO_UH_FLOATS;
     a.amax_out = ext ? ext->out_amax : nullptr;
     if (ext) ext->out_recorded = ext->out_amax != nullptr;
     if (ext && ext->in_amax) a.amax_in = ext->in_amax;
@@ -628,20 +644,31 @@ int pcc_conv_wino_f16s(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
         { const int rc = pcc_block_amax(ctx, in, d->N, (size_t)d->D * d->H * d->W * d->Cin, am, st); if (rc != PCC_OK) return rc; }
         a.amax_in = am;
     }
-    const int base = d->N * a.nty * a.ntx * G;
+    const int base = d->N * a.nty * a.ntx * NG;
     int zs = 1;
-    const int min_zlen = G >= 2 ? 4 : 8;
+    const int min_zlen = NG >= 2 ? 4 : 8;
     while (base * zs < ctx->num_cu && d->D % (zs * 2) == 0 && d->D / (zs * 2) >= min_zlen) zs *= 2;
     a.zsplit = zs; a.zlen = d->D / zs;
     const int nwg = base * zs;
     typedef void (*kern_t)(WinoArgs, int);
-    static const kern_t kerns[6] = {conv16_wino_f16s_kernel<false, false, 1>, conv16_wino_f16s_kernel<true, false, 1>,
-                                    conv16_wino_f16s_kernel<false, true, 1>, conv16_wino_f16s_kernel<true, true, 1>,
-                                    conv16_wino_f16s_kernel<false, false, 2>, conv16_wino_f16s_kernel<true, false, 2>};
-    const kern_t kern = G == 1 ? kerns[((d->flags & PCC_CONV_RELU) ? 1 : 0) + ((d->flags & PCC_CONV_CLIP01) ? 2 : 0)] : kerns[4 + ((d->flags & PCC_CONV_RELU) ? 1 : 0)];
+    const bool relu = (d->flags & PCC_CONV_RELU) != 0;
     const int lds = f16s_lds_bytes(G);
-    { const int rc = pcc_enable_big_lds((const void*)kern, lds); if (rc != PCC_OK) return rc; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds, st, a, nwg);
-    PCC_CHECK_HIP(hipGetLastError());
-    return PCC_OK;
+    auto launch1 = [&](kern_t kern, const WinoArgs& aa) -> int {
+        { const int rc = pcc_enable_big_lds((const void*)kern, lds); if (rc != PCC_OK) return rc; }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds, st, aa, nwg);
+        PCC_CHECK_HIP(hipGetLastError());
+        return PCC_OK;
+    };
+    if (NG == 1) {
+        static const kern_t k1[4] = {conv16_wino_f16s_kernel<false, false, 1>, conv16_wino_f16s_kernel<true, false, 1>,
+                                     conv16_wino_f16s_kernel<false, true, 1>, conv16_wino_f16s_kernel<true, true, 1>};
+        return launch1(k1[(relu ? 1 : 0) + ((d->flags & PCC_CONV_CLIP01) ? 2 : 0)], a);
+    }
+    if (NG == 2) return launch1(relu ? (kern_t)conv16_wino_f16s_kernel<true, false, 2> : (kern_t)conv16_wino_f16s_kernel<false, false, 2>, a);
+    // NG == 4: cin groups {0, 1} -> raw partial sums, then {2, 3} + partial sums -> bias (in the accumulators) / ReLU / residual
+    WinoArgs p0 = a;
+    p0.flags = 0; p0.bias = nullptr; p0.res = nullptr; p0.amax_out = nullptr;
+    { const int rc = launch1((kern_t)conv16_wino_f16s_kernel<false, false, 2>, p0); if (rc != PCC_OK) return rc; }
+    a.ig0 = 2; a.ico = 32;
+    return launch1(relu ? (kern_t)conv16_wino_f16s_kernel<true, false, 2, true> : (kern_t)conv16_wino_f16s_kernel<false, false, 2, true>, a);
 }

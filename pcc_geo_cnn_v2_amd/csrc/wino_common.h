@@ -57,6 +57,7 @@ struct WinoArgs {
     const unsigned* amax_in = nullptr;
     unsigned* amax_out = nullptr;
     const float* utail = nullptr;
+    int ig0 = 0;        // first cin group this launch marches (the 64-channel layers run as two launches of two groups)
 };
 
 // Measured on MI355X (tools/ubench/mfma_valu.hip): a wave's VALU instructions do NOT overlap with its own fp32 MFMAs
