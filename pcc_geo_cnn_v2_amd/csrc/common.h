@@ -129,6 +129,13 @@ void pcc_tr2m_bf16_pack(int Cin, int Cout, const float* w_tr2g, float* out);
 bool pcc_tr2m_bf16_covers(const pcc_conv_desc* d);
 int pcc_conv_tr2m_bf16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_split, const float* bias, float* out,
                        pcc_conv_ext* ext, hipStream_t st);
+// the same march with two fp16 pieces under a per-block pre-scale for 32 -> 16 (conv_tr2m_f16s.hip, round 6)
+constexpr int PCC_TR2M_F16S_TAIL = 64;      // floats behind the fragments, [0] = the weight scale
+size_t pcc_tr2m_f16s_packed_floats(int Cin, int Cout);
+void pcc_tr2m_f16s_pack(int Cin, int Cout, const float* w_tr2g, float* out);
+bool pcc_tr2m_f16s_covers(const pcc_conv_desc* d);
+int pcc_conv_tr2m_f16s(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_f16s, const float* bias, float* out,
+                       pcc_conv_ext* ext, hipStream_t st);
 // the march in the fp16 mode (conv_tr2m_f16.hip, round 5): fp32 input, fp16 MFMA, fp16 output (PCC_CONV_F16 | PCC_CONV_OUT16), 32 -> 16 and 64 -> 32
 bool pcc_tr2m_f16_covers(const pcc_conv_desc* d);
 int pcc_conv_tr2m_f16(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_tr2g, const float* bias, void* out,

@@ -1727,6 +1727,7 @@ PCC_API int pcc_conv_mfma_supported(const pcc_conv_desc* d) {
 #define NGROUPS(c) ((c) / 16)
 // stride-2 transposed k3 layers that carry a split-bf16 image behind their two fp32 images: 32 -> 16 (conv_tr2m_bf16.hip), 64 -> 32 and
 // 64 -> 64 (conv_tr2_split_kernel, conv_split.hip)
+static bool tr2_has_f16s_image(int Cin, int Cout) { return Cin == 32 && Cout == 16; }
 static bool tr2_has_split_image(int Cin, int Cout) { return (Cin == 32 && Cout == 16) || (Cin == 64 && (Cout == 32 || Cout == 64)); }
 
 // two-piece fp16 image of U behind everything else of a k3 stride-1 layer (conv_wino_f16s.hip): the 16- and 32-channel layers carry one
@@ -1751,7 +1752,8 @@ PCC_API size_t pcc_conv_packed_floats(const pcc_conv_desc* d) {
                        wino_f16s_floats(d->Cin);                                            // + the two-piece fp16 image of U (conv_wino_f16s.hip)
             return k3 * d->Cin * d->Cout;
         case K_TR2:     // k3: second copy in the order of conv_tr2g_kernel; 32 -> 16: + its split-bf16 image (conv_tr2m_bf16.hip)
-            return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1) + (d->k == 3 && tr2_has_split_image(d->Cin, d->Cout) ? pcc_tr2m_bf16_packed_floats(d->Cin, d->Cout) : 0);
+            return k3 * d->Cin * d->Cout * (d->k == 3 ? 2 : 1) + (d->k == 3 && tr2_has_split_image(d->Cin, d->Cout) ? pcc_tr2m_bf16_packed_floats(d->Cin, d->Cout) : 0) +
+                   (d->k == 3 && tr2_has_f16s_image(d->Cin, d->Cout) ? pcc_tr2m_f16s_packed_floats(d->Cin, d->Cout) : 0);      // 32 -> 16: + its two-piece fp16 image (conv_tr2m_f16s.hip)
         case K_CIN1: return (size_t)d->k * d->k * ((d->k + 3) / 4) * 4 * d->Cout;
         case K_COUT1: return k3 * d->Cin;
         case K_COUT1M: return 2 * 64 * 4;
@@ -1839,6 +1841,7 @@ PCC_API int pcc_conv_pack_weights(const pcc_conv_desc* d, const float* w, float*
                                         Wf(kz, ky, kx, g * 16 + 4 * (lane >> 4) + j, ct * 16 + (lane & 15));
             }
             if (tr2_has_split_image(Cin, Cout)) pcc_tr2m_bf16_pack(Cin, Cout, pg, pg + (size_t)27 * Cin * Cout);
+            if (tr2_has_f16s_image(Cin, Cout)) pcc_tr2m_f16s_pack(Cin, Cout, pg, pg + (size_t)27 * Cin * Cout + pcc_tr2m_bf16_packed_floats(Cin, Cout));
         }
     } else if (p.kind == K_CIN1) {
         // [kz][ky][kxg][ct][lane] : kx = kxg*4 + (lane>>4) (zero beyond k), cout = ct*16 + (lane&15)
@@ -1895,10 +1898,23 @@ static int k3s1_route(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     return 2;
 }
 
+// the 32 -> 16 stride-2 transposed march takes its two-piece fp16 form (given that the dispatch reaches the marching kernels)
+static bool tr2m_f16s_taken(const pcc_ctx* ctx, const pcc_conv_desc* d) {
+    return pcc_tr2m_f16s_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2 | PCC_NUM_NO_F16S);
+}
+// the dispatch of pcc_conv3d_mfma_thr for a k3 stride-2 transposed layer reaches the marching kernels (conv_tr2m*.hip)
+static bool tr2_reaches_march(const pcc_ctx* ctx, const pcc_conv_desc* d) {
+    if (d->k != 3) return false;
+    if (d->impl == PCC_IMPL_AUTO && !ctx->num(PCC_NUM_NO_TR2M) && pcc_tr2m_f16_covers(d)) return false;
+    if (d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2)) return false;
+    return !ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d));
+}
+
 // Does the kernel picked for this layer take the fp16-split path (it then wants the per-block max of its input)?
 bool pcc_conv_wants_amax(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     if (d->flags & (PCC_CONV_IN16 | PCC_CONV_OUT16)) return false;
     const Plan p = make_plan(d);
+    if (p.kind == K_TR2) return tr2_reaches_march(ctx, d) && tr2m_f16s_taken(ctx, d);
     if (p.kind != K_FWD || !(pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && (p.flip ? 1 : d->stride) == 1)) return false;
     return k3s1_route(ctx, d) == 4;
 }
@@ -1929,7 +1945,8 @@ PCC_API int pcc_conv_kernel_family(pcc_ctx* ctx, const pcc_conv_desc* d, char* b
         else if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
             name = "conv_tr2_split (parity classes, bf16 x 3)";
         else if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d)))
-            name = pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2) ? "conv_tr2m_bf16 (z march, bf16 x 3)" : "conv_tr2m (z march, exact fp32 MFMA)";
+            name = tr2m_f16s_taken(ctx, d) ? "conv_tr2m_f16s (z march, fp16 x 2 under a per-block pre-scale)"
+                   : pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2) ? "conv_tr2m_bf16 (z march, bf16 x 3)" : "conv_tr2m (z march, exact fp32 MFMA)";
     } else if (p.kind == K_CIN1) name = "conv_cin1 (exact fp32 MFMA)";
     else if (p.kind == K_COUT1M) name = "conv_cout1_mfma (exact fp32 MFMA)";
     else if (p.kind == K_COUT1) name = "conv_cout1 (fp32 VALU)";
@@ -2002,6 +2019,8 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
         // tiled conv_tr2g_kernel, PCC_TR2M=1 takes the marching kernel wherever it is eligible (A/B runs, tests)
         if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {
             // 32 -> 16: split-bf16 operands on the bf16 MFMA pipe (conv_tr2m_bf16.hip); PCC_NO_SPLIT=1 / PCC_NO_SPLIT_TR2=1: exact fp32 (A/B)
+            if (tr2m_f16s_taken(ctx, d))      // two fp16 pieces under a per-block pre-scale (round 6); PCC_NO_F16S=1: the three-piece bf16 march
+                return pcc_conv_tr2m_f16s(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co + pcc_tr2m_bf16_packed_floats(ci, co), bias, out, ext, st);
             if (pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
                 return pcc_conv_tr2m_bf16(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, ext, st);
             return pcc_conv_tr2m(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
