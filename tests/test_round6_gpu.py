@@ -27,3 +27,72 @@ def test_bench_configs2_runs_one_cloud_through_the_sharded_entry_points(force_di
     # a one-rank group takes the unsharded path (sharding.world_info() == (0, 1)): no collective is issued, and the line says so
     assert d['final_collectives_calls_per_step'] == 0 and d['final_collectives_ms'] == 0
     assert set(d['config']['phase_ms_per_step_rank0']) == {'encode', 'handover', 'decode'}
+
+
+def _ctx():
+    from pcc_geo_cnn_v2_amd import ops
+    return ops.get_context(torch.device('cuda', 0))
+
+
+def test_kernel_family_names_the_round6_kernels_and_follows_the_numerics_switches():
+    """pcc_conv_kernel_family (include/pcc_geo.h): the c3p layers that VERDICT r05 item 1 asked to move take the two-piece fp16 kernels by
+    default, PCC_NO_F16S=1 (numerics switch no_f16s) gives round 5's kernels, PCC_NO_SPLIT=1 the exact-fp32 ones -- a function of the layer
+    shape and the context only, never of the batch (encoder and decoder chunks must take the same kernel)."""
+    import ctypes
+    from pcc_geo_cnn_v2_amd import _lib as L
+    ctx = _ctx()
+
+    def fam(N, D, cin, cout, stride=1, tr=1):
+        d = L.ConvDesc(N=N, D=D, H=D, W=D, Cin=cin, Cout=cout, k=3, stride=stride, transposed=tr, flags=L.PCC_CONV_BIAS | L.PCC_CONV_RELU)
+        buf = ctypes.create_string_buffer(96)
+        L.check(L.lib().pcc_conv_kernel_family(ctx.handle, ctypes.byref(d), buf, 96), 'pcc_conv_kernel_family')
+        return buf.value.decode()
+    for N in (1, 32):
+        assert fam(N, 64, 16, 16).startswith('conv16_wino_f16s') and fam(N, 32, 32, 32).startswith('conv16_wino_f16s') and fam(N, 16, 64, 64).startswith('conv16_wino_f16s')
+        assert fam(N, 32, 32, 16, 2).startswith('conv_tr2m_f16s') and fam(N, 8, 64, 64).startswith('conv_k3s1_split') and fam(N, 16, 32, 32).startswith('conv_k3s1_split32')
+    with ctx.numerics_override(no_f16s=True):
+        assert fam(32, 64, 16, 16).startswith('conv16_wino_bf16') and fam(32, 32, 32, 32).startswith('conv16_wino (') and fam(32, 16, 64, 64).startswith('conv_k3s1_split (')
+        assert fam(32, 32, 32, 16, 2).startswith('conv_tr2m_bf16')
+    with ctx.numerics_override(no_split=True):
+        assert fam(32, 64, 16, 16).startswith('conv16_wino (') and fam(32, 32, 32, 16, 2).startswith('conv_tr2m (')
+
+
+@pytest.mark.parametrize('C,D,N', [(16, 32, 3), (32, 32, 2), (64, 16, 3)])
+def test_two_piece_fp16_layers_scale_per_block_and_not_per_launch(C, D, N):
+    """conv_wino_f16s.hip: the pre-scale follows the maximum of EACH 64^3 block (/root/reference/src/model_transforms.py:62-81 run block by
+    block in the reference, src/model_types.py:192-212): a block's output bits do not depend on what else is in the launch -- even when a
+    neighbour is 2^30 times larger or all zero -- and scaling ONE block by a power of two scales that block's output bit for bit."""
+    from pcc_geo_cnn_v2_amd import ops, _lib as L
+    ctx = _ctx()
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((3, 3, 3, C, C)) / np.sqrt(27 * C)).astype(np.float32)
+    layer = ops.ConvLayer(w, None, 1, True, True)
+    x = torch.from_numpy(rng.standard_normal((N, D, D, D, C)).astype(np.float32)).to(ctx.device)
+    base = ops.conv3d(ctx, x, layer, impl=L.PCC_IMPL_WINOGRAD)
+    y = x.clone()
+    y[0] *= 2.0 ** 30
+    y[N - 1] = 0
+    got = ops.conv3d(ctx, y, layer, impl=L.PCC_IMPL_WINOGRAD)
+    assert torch.equal(got[0], base[0] * 2.0 ** 30) and torch.count_nonzero(got[N - 1]) == 0
+    for b in range(1, N - 1):
+        assert torch.equal(got[b], base[b])
+    assert torch.equal(ops.conv3d(ctx, x[1:2].contiguous(), layer, impl=L.PCC_IMPL_WINOGRAD), base[1:2])
+
+
+def test_recorded_block_maxima_equal_a_reduction_over_the_tensor():
+    """The side channel of the fp16-split kernels (csrc/common.h, pcc_conv_ext): inside pcc_network_forward the kernel that writes a tensor
+    records max |x| per block; chained through pcc_conv3d the library reduces the tensor itself.  Both must give the same bits: the c3p
+    synthesis transform through the network call == layer by layer (this is what makes encoder-side and decoder-side x_hat equal whatever
+    API level a caller uses)."""
+    from pcc_geo_cnn_v2_amd import ops, _lib as L
+    from pcc_geo_cnn_v2_amd.model_transforms import SynthesisTransformProgressiveV2, init_transform
+    ctx = _ctx()
+    tr = init_transform(SynthesisTransformProgressiveV2(64, data_format='channels_last'), 64, np.random.default_rng(1))
+    x = torch.from_numpy(np.random.default_rng(2).standard_normal((2, 8, 8, 8, 64)).astype(np.float32)).to(ctx.device)
+    a = tr.forward_ndhwc(ctx, x)
+    os.environ['PCC_LAYERWISE'] = '1'
+    try:
+        b = tr.forward_ndhwc(ctx, x)
+    finally:
+        del os.environ['PCC_LAYERWISE']
+    assert torch.equal(a, b) and torch.isfinite(a).all()

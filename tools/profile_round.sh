@@ -24,12 +24,13 @@ pmc wino16 32 64 16 16 3 1 1 res
 python $R/tools/summarize_round.py $TAG --traffic-only && cp $R/profiles/dominant_kernel_traffic.json $OUT/dominant_kernel_traffic.json
 # (1) per-kernel time of the benchmark command: 15 steps, all of them traced and counted (no set-up priming, no A/B, no secondary)
 TRACE_CMD="python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-ab"
-echo "PCC_BENCH_NO_PRIME=1 $TRACE_CMD" > $OUT/trace_cmd.txt; echo 15 > $OUT/trace_steps.txt
-PCC_BENCH_NO_PRIME=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 180 python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-ab > $OUT/bench_profiled.log 2>&1
+echo "PCC_BENCH_NO_STEP_PROFILE=1 PCC_BENCH_NO_PRIME=1 $TRACE_CMD" > $OUT/trace_cmd.txt; echo 15 > $OUT/trace_steps.txt
+PCC_BENCH_NO_STEP_PROFILE=1 PCC_BENCH_NO_PRIME=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- timeout 180 python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-ab > $OUT/bench_profiled.log 2>&1
 export PCC_NO_SPLIT=1; pmc wino16_fp32 32 64 16 16 3 1 1 res; unset PCC_NO_SPLIT
 export PCC_NO_F16S=1; pmc wino16_bf16 32 64 16 16 3 1 1 res; unset PCC_NO_F16S
 pmc cin32 32 32 32 32 3 1 1 res
 pmc cin64 32 16 64 64 3 1 1 res
+mkdir -p $OUT/cin64_first && for d in fetch write sq lds; do cp -r $OUT/cin64/$d $OUT/cin64_first/; done; cp $OUT/cin64/time.log $OUT/cin64_first/time.log
 pmc tr2m 32 32 32 16 3 2 1
 pmc tr2g 32 16 64 32 3 2 1
 pmc cout1 32 64 16 1 3 1 1
