@@ -1727,7 +1727,7 @@ PCC_API int pcc_conv_mfma_supported(const pcc_conv_desc* d) {
 #define NGROUPS(c) ((c) / 16)
 // stride-2 transposed k3 layers that carry a split-bf16 image behind their two fp32 images: 32 -> 16 (conv_tr2m_bf16.hip), 64 -> 32 and
 // 64 -> 64 (conv_tr2_split_kernel, conv_split.hip)
-static bool tr2_has_f16s_image(int Cin, int Cout) { return Cin == 32 && Cout == 16; }
+static bool tr2_has_f16s_image(int Cin, int Cout) { return (Cin == 32 && Cout == 16) || (Cin == 64 && Cout == 32); }
 static bool tr2_has_split_image(int Cin, int Cout) { return (Cin == 32 && Cout == 16) || (Cin == 64 && (Cout == 32 || Cout == 64)); }
 
 // two-piece fp16 image of U behind everything else of a k3 stride-1 layer (conv_wino_f16s.hip): the 16- and 32-channel layers carry one
@@ -1898,23 +1898,29 @@ static int k3s1_route(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     return 2;
 }
 
-// the 32 -> 16 stride-2 transposed march takes its two-piece fp16 form (given that the dispatch reaches the marching kernels)
-static bool tr2m_f16s_taken(const pcc_ctx* ctx, const pcc_conv_desc* d) {
-    return pcc_tr2m_f16s_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2 | PCC_NUM_NO_F16S);
-}
-// the dispatch of pcc_conv3d_mfma_thr for a k3 stride-2 transposed layer reaches the marching kernels (conv_tr2m*.hip)
-static bool tr2_reaches_march(const pcc_ctx* ctx, const pcc_conv_desc* d) {
-    if (d->k != 3) return false;
-    if (d->impl == PCC_IMPL_AUTO && !ctx->num(PCC_NUM_NO_TR2M) && pcc_tr2m_f16_covers(d)) return false;
-    if (d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2)) return false;
-    return !ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d));
+// The dispatch rules of the k3 stride-2 transposed layers (shape + context state only), in the order pcc_conv3d_mfma_thr applies them:
+// 0 = tiled exact-fp32 kernels, 1 = z march in the fp16 MODE (conv_tr2m_f16.hip), 2 = z march with two fp16 pieces (conv_tr2m_f16s.hip:
+// 32 -> 16, 64 -> 32 on grids of 16-multiples), 3 = parity-class tiles with three bf16 pieces (conv_tr2_split_kernel), 4 = z march with
+// three bf16 pieces (32 -> 16), 5 = z march exact fp32
+static int tr2_route(const pcc_ctx* ctx, const pcc_conv_desc* d) {
+    if (d->k != 3) return 0;
+    const bool autoi = d->impl == PCC_IMPL_AUTO;
+    if (autoi && !ctx->num(PCC_NUM_NO_TR2M) && pcc_tr2m_f16_covers(d)) return 1;
+    const bool plain = !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16));
+    if (autoi && plain && !ctx->num(PCC_NUM_NO_TR2M | PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2 | PCC_NUM_NO_F16S) && pcc_tr2m_f16s_covers(d)) return 2;
+    if (autoi && plain && pcc_tr2_split_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2)) return 3;
+    if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {
+        if (plain && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2 | PCC_NUM_NO_F16S) && pcc_tr2m_f16s_covers(d)) return 2;      // (PCC_IMPL_MFMA callers)
+        return pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2) ? 4 : 5;
+    }
+    return 0;
 }
 
 // Does the kernel picked for this layer take the fp16-split path (it then wants the per-block max of its input)?
 bool pcc_conv_wants_amax(const pcc_ctx* ctx, const pcc_conv_desc* d) {
     if (d->flags & (PCC_CONV_IN16 | PCC_CONV_OUT16)) return false;
     const Plan p = make_plan(d);
-    if (p.kind == K_TR2) return tr2_reaches_march(ctx, d) && tr2m_f16s_taken(ctx, d);
+    if (p.kind == K_TR2) return tr2_route(ctx, d) == 2;
     if (p.kind != K_FWD || !(pcc_wino_channels(d->Cin, d->Cout) && d->k == 3 && (p.flip ? 1 : d->stride) == 1)) return false;
     return k3s1_route(ctx, d) == 4;
 }
@@ -1940,13 +1946,9 @@ PCC_API int pcc_conv_kernel_family(pcc_ctx* ctx, const pcc_conv_desc* d, char* b
             }
         }
     } else if (p.kind == K_TR2) {
-        name = "conv_tr2 (exact fp32 MFMA)";
-        if (k == 3 && d->impl == PCC_IMPL_AUTO && !ctx->num(PCC_NUM_NO_TR2M) && pcc_tr2m_f16_covers(d)) name = "conv_tr2m_f16 (z march, f16 MFMA)";
-        else if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
-            name = "conv_tr2_split (parity classes, bf16 x 3)";
-        else if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d)))
-            name = tr2m_f16s_taken(ctx, d) ? "conv_tr2m_f16s (z march, fp16 x 2 under a per-block pre-scale)"
-                   : pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2) ? "conv_tr2m_bf16 (z march, bf16 x 3)" : "conv_tr2m (z march, exact fp32 MFMA)";
+        static const char* const tn[6] = {"conv_tr2 (exact fp32 MFMA)", "conv_tr2m_f16 (z march, f16 MFMA)", "conv_tr2m_f16s (z march, fp16 x 2 under a per-block pre-scale)",
+                                          "conv_tr2_split (parity classes, bf16 x 3)", "conv_tr2m_bf16 (z march, bf16 x 3)", "conv_tr2m (z march, exact fp32 MFMA)"};
+        name = tn[tr2_route(ctx, d)];
     } else if (p.kind == K_CIN1) name = "conv_cin1 (exact fp32 MFMA)";
     else if (p.kind == K_COUT1M) name = "conv_cout1_mfma (exact fp32 MFMA)";
     else if (p.kind == K_COUT1) name = "conv_cout1 (fp32 VALU)";
@@ -2007,23 +2009,15 @@ int pcc_conv3d_mfma_thr(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, c
         PCC_CASE_FWD(16, 32, 3, 2) PCC_CASE_FWD(32, 64, 3, 2) PCC_CASE_FWD(64, 64, 3, 2)
         PCC_CASE_FWD(32, 32, 3, 2) PCC_CASE_FWD(32, 32, 5, 2)
     } else if (p.kind == K_TR2) {
-        // fp16 mode, fp16 hand-over: the z march with fp16 MFMAs (conv_tr2m_f16.hip, round 5); shape-only rule, PCC_NO_TR2M=1: the tiled kernel (A/B)
-        if (k == 3 && d->impl == PCC_IMPL_AUTO && !ctx->num(PCC_NUM_NO_TR2M) && pcc_tr2m_f16_covers(d))
-            return pcc_conv_tr2m_f16(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
-        // 64 -> 32 / 64 -> 64: split-bf16 operands on the bf16 MFMA pipe (conv_tr2_split_kernel); shape-only rule, PCC_NO_SPLIT=1 /
-        // PCC_NO_SPLIT_TR2=1: the exact-fp32 kernels below (A/B)
-        if (k == 3 && d->impl == PCC_IMPL_AUTO && pcc_tr2_split_covers(d) && !(d->flags & (PCC_CONV_F16 | PCC_CONV_OUT16)) &&
-            !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
-            return pcc_conv_tr2_split(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, ext, st);
-        // z-marching kernel (conv_tr2m.hip) for the 32 -> 16 / 64 -> 32 layers on grids of 16-multiples.  PCC_NO_TR2M=1 keeps the
-        // tiled conv_tr2g_kernel, PCC_TR2M=1 takes the marching kernel wherever it is eligible (A/B runs, tests)
-        if (!ctx->num(PCC_NUM_NO_TR2M) && (ctx->num(PCC_NUM_TR2M) ? pcc_tr2m_eligible(d) : pcc_tr2m_preferred(ctx, d))) {
-            // 32 -> 16: split-bf16 operands on the bf16 MFMA pipe (conv_tr2m_bf16.hip); PCC_NO_SPLIT=1 / PCC_NO_SPLIT_TR2=1: exact fp32 (A/B)
-            if (tr2m_f16s_taken(ctx, d))      // two fp16 pieces under a per-block pre-scale (round 6); PCC_NO_F16S=1: the three-piece bf16 march
-                return pcc_conv_tr2m_f16s(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co + pcc_tr2m_bf16_packed_floats(ci, co), bias, out, ext, st);
-            if (pcc_tr2m_bf16_covers(d) && !ctx->num(PCC_NUM_NO_SPLIT | PCC_NUM_NO_SPLIT_TR2))
-                return pcc_conv_tr2m_bf16(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, ext, st);
-            return pcc_conv_tr2m(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
+        // tr2_route: fp16-mode march | two-piece fp16 march (32 -> 16, 64 -> 32; PCC_NO_F16S=1 off) | parity-class tiles, bf16 x 3 (64 -> 32 / 64 -> 64;
+        // PCC_NO_SPLIT=1 / PCC_NO_SPLIT_TR2=1 off) | bf16 x 3 march (32 -> 16) | exact-fp32 march (PCC_NO_TR2M=1: the tiled kernels below)
+        switch (tr2_route(ctx, d)) {
+            case 1: return pcc_conv_tr2m_f16(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
+            case 2: return pcc_conv_tr2m_f16s(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co + pcc_tr2m_bf16_packed_floats(ci, co), bias, out, ext, st);
+            case 3: return pcc_conv_tr2_split(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, ext, st);
+            case 4: return pcc_conv_tr2m_bf16(ctx, d, in, w_packed + (size_t)2 * 27 * ci * co, bias, out, ext, st);
+            case 5: return pcc_conv_tr2m(ctx, d, in, w_packed + (size_t)27 * ci * co, bias, out, st);
+            default: break;
         }
         PCC_CASE_TR2(64, 64, 3) PCC_CASE_TR2(64, 32, 3) PCC_CASE_TR2(32, 16, 3) PCC_CASE_TR2(32, 32, 3)
         PCC_CASE_TR2(32, 32, 5)

@@ -8,6 +8,11 @@
 // of 128 B-operand registers, 96 instead of 160 bytes per staged voxel (30 KB tile), 16 instead of 32 LDS reads per micro-step -- and the
 // split of a staged item is 2 packed muls (the scale) + 2 cvt_pk + 4 fma_mix instead of 20 ops with DOT hazards.  The scale is undone
 // in the epilogue (one packed mul pair per stored float4; ReLU commutes with it), the bias enters the accumulators scaled by su s.
+// Weights (late round 6): LDS-resident, lane-contiguous [cin group][lane][27 taps][4 h | 4 l] fp16 + 8 B pad (440 B per lane), read by
+// ds_read2_b64 with offset0 == offset1 -- the 8 bytes of a piece arrive twice in four consecutive registers, the duplicated operands
+// [Wh | Wh] / [Wl | Wl] without a duplicated image (conv_wino_f16s.hip): 27.5 KB per cin group instead of 54, so the 64 -> 32 layer
+// (NG = 4: 110 KB + the 30 KB tile) marches too.  Those reads are inline asm (the compiler inserts no waits for them); inside the tap
+// loop they are the ONLY LDS operations, two taps ahead, so "at most 4 younger reads outstanding" is the wait in front of every tap.
 // Everything else -- /root/reference/src/model_transforms.py:78 inside :126-137, parity decomposition, three accumulator sets, epilogue
 // under the first taps of the next plane, compile-time plane parity, the recorded maximum of the output -- is conv_tr2m_bf16.hip's.
 #include <cmath>
@@ -43,6 +48,14 @@ __device__ __forceinline__ u32x4 split_quad(const f32x4& v, const f32x2& s2) {
                  "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(l23) : "v"(h23), "v"(hi[0]), "v"(hi[1]));
     return (u32x4){h01, h23, l01, l23};
 }
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read2_dup(unsigned addr) {      // {8 bytes at addr + OFF} twice
+    u32x4 v;
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%2" : "=v"(v) : "v"(addr), "n"(OFF / 8));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_w(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 __device__ __forceinline__ f32x4 mul4s(const f32x4& a, const f32x2& s) {
     f32x2 lo, hi;
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(s));
@@ -88,11 +101,13 @@ constexpr int VSB = 96;                                 // bytes per voxel of th
                                                         // ds_read_b128 lane groups and the 8-lane groups of the staging ds_write_b128: no conflicts)
 constexpr int TILE_BYTES = ITEMS * 64 * VSB;            // 30720: 320 voxel slots (289 used; the items past the tile write zeros into the rest)
 constexpr int W_BASE = TILE_BYTES;                      // one tile, then the weights
+constexpr int WL_LANE = 27 * 16 + 8;                    // bytes per lane and cin group: 27 taps x (4 h + 4 l fp16) + 8 pad (440 = 55 x 8: 32 lanes on 64 distinct banks)
+constexpr int WG_BYTES = 64 * WL_LANE;                  // 28160 per (cin group, cout tile)
 constexpr int ROWB = LXY * VSB;                         // bytes per tile row
 
 struct Tr2mArgs {
     const float* in;
-    const float* w;      // two-piece image in conv_tr2g order: [cin group][27 taps, class-major][cout tile][operand][64 lanes][8 fp16], operand 0 = [Wh | Wh], 1 = [Wl | Wl]
+    const float* w;      // two-piece image: [cout tile][cin group][lane][27 taps, class-major (conv_tr2g order)][4 h | 4 l fp16] + 8 B pad per lane
     const float* wtail;  // [0] = su, the power of two the weight pieces were scaled by
     const unsigned* amax_in;      // per-block maxima of the input (PCC_AMAX_SLOTS partial maxima per block)
     const float* bias;
@@ -147,12 +162,12 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_f16s_kernel(Tr2mArgs a, int n
     const unsigned HWI = (unsigned)(HW * CIN * 4);
     const float* in_n = a.in + (size_t)n * a.D * HW * CIN;
 
-    // ---- split weights of this cout tile -> LDS (resident): NG x 27 fragments of 2 KB ([Wh | Wm] then [Wl | Wh]), fragment (g, sq) at
-    //      W_BASE + (g * 27 + sq) * 2 KB
+    // ---- the weight pieces of this cout tile -> LDS (resident): NG x 27.5 KB, one linear copy
     {
-        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)(NG * 27 * a.nct) * 2048u);
-        for (int p = wave; p < NG * 27 * 2; p += 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + W_BASE + p * 1024), 16, lane * 16, ((p >> 1) * a.nct + ct) * 2048 + (p & 1) * 1024, 0, 0);
+        constexpr int WBYTES = NG * WG_BYTES, NCH = (WBYTES + 1023) / 1024;
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w + (size_t)ct * (WBYTES / 4), (unsigned)WBYTES);      // beyond the image: zeros
+        for (int p = wave; p < NCH; p += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + W_BASE + p * 1024), 16, lane * 16, p * 1024, 0, 0);
     }
     // ---- scales (wave-uniform)
     const float su = a.wtail[0];
@@ -196,7 +211,7 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_f16s_kernel(Tr2mArgs a, int n
     unsigned ba[2];
 #pragma unroll
     for (int dxi = 0; dxi < 2; ++dxi) ba[dxi] = (unsigned)((4 * wave * LXY + v + 1 - dxi) * VSB + cq * 16);
-    unsigned wa = (unsigned)(W_BASE + lane * 16);      // + cin group * 54 KB (per micro-step), + tap * 2 KB (immediate)
+    unsigned wa = (unsigned)(unsigned long long)(lds_ptr)smem + (unsigned)(W_BASE + lane * WL_LANE);      // absolute; + cin group * 27.5 KB (per micro-step), + tap * 16 B (immediate)
 
     // ---- epilogue addressing: lane writes couts 4 cq .. 4 cq + 3 (of this cout tile) of output voxel (2 z + pz, 2 y + py, 2 x + px)
     const int OH = 2 * a.H, OW = 2 * a.W;
@@ -235,12 +250,15 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_f16s_kernel(Tr2mArgs a, int n
                 for (int i = 0; i < 4; ++i)
                     b1[dyi][dxi][i] = ldsu(ba[dxi] + (unsigned)((i + 1 - dyi) * ROWB));
     };
-    auto load_w = [&](int slot, int sq) __attribute__((always_inline)) {
-        wf1[slot] = ldsu(wa + (unsigned)(sq * 2048));
-        wf2[slot] = ldsu(wa + (unsigned)(sq * 2048 + 1024));
+    auto load_w = [&](auto slot_tag, auto sq_tag) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_tag)::value, sq = decltype(sq_tag)::value;
+        wf2[slot] = lds_read2_dup<sq * 16 + 8>(wa);
+        wf1[slot] = lds_read2_dup<sq * 16>(wa);
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
     load_b();
-    load_w(0, tap_of(18).sq); load_w(1, tap_of(19).sq);      // step 0 is the halo plane: its first tap is 18 (ring slot = (t - T0) % 3)
+    load_w(I0{}, std::integral_constant<int, tap_of(18).sq>{}); load_w(I1{}, std::integral_constant<int, tap_of(19).sq>{});      // step 0 is the halo plane: its first tap is 18 (ring slot = (t - T0) % 3)
 
     // wave-uniform march state
     int s = 0, c = 0;                                 // input plane step / cin group of the current micro-step
@@ -274,7 +292,9 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_f16s_kernel(Tr2mArgs a, int n
             constexpr int t = decltype(t_tag)::value + T0;
             constexpr Tap T = tap_of(t);
             // weight fragment of the next tap (wraps to tap 0 of the next micro-step: loaded after the barrier instead)
-            if constexpr (t + 2 < 27) load_w((t + 2 - T0) % 3, tap_of(t + 2).sq);
+            if constexpr (t + 2 < 27) load_w(std::integral_constant<int, (t + 2 - T0) % 3>{}, std::integral_constant<int, tap_of(t + 2).sq>{});
+            // this tap's fragments were requested two taps ago; younger LDS reads: the fragments of taps t + 1 and t + 2 (two each)
+            lgkm_wait_w<(t + 2 < 27 ? 4 : t + 1 < 27 ? 2 : 0)>(wf1[(t - T0) % 3], wf2[(t - T0) % 3]);
             constexpr bool open = FIRST && T.opens && T.kz != 0;     // first tap of a class of the odd / even_next set in this plane
             // two MFMAs per row, term outermost: a dependent MFMA is four issue slots away
 #pragma unroll
@@ -316,11 +336,11 @@ __global__ void __launch_bounds__(NT, 1) conv_tr2m_f16s_kernel(Tr2mArgs a, int n
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt / expcnt untouched (stores and the raw loads stay in flight)
         __syncthreads();
         // ---- advance (wave-uniform) and fetch the operands of the next micro-step
-        if (++c == NG) { c = 0; ++s; out_pl += 2ull * PLANE_O; wa -= (unsigned)((NG - 1) * 27 * 2048); } else wa += 27u * 2048u;
+        if (++c == NG) { c = 0; ++s; out_pl += 2ull * PLANE_O; wa -= (unsigned)((NG - 1) * WG_BYTES); } else wa += (unsigned)WG_BYTES;
         load_b();
-        // first weight fragment of the next micro-step (buffer parity follows its first tap: 0, or 18 inside the halo plane)
-        if (s == 0) { load_w(0, tap_of(18).sq); load_w(1, tap_of(19).sq); }
-        else { load_w(0, tap_of(0).sq); load_w(1, tap_of(1).sq); }
+        // first weight fragments of the next micro-step (buffer parity follows its first tap: 0, or 18 inside the halo plane)
+        if (s == 0) { load_w(I0{}, std::integral_constant<int, tap_of(18).sq>{}); load_w(I1{}, std::integral_constant<int, tap_of(19).sq>{}); }
+        else { load_w(I0{}, std::integral_constant<int, tap_of(0).sq>{}); load_w(I1{}, std::integral_constant<int, tap_of(1).sq>{}); }
     };
     // one input plane = NG micro-steps, unrolled (a run-time loop over the middle ones made the register allocator shuttle the
     // accumulators between AccVGPRs and VGPRs at the loop boundary)
@@ -372,9 +392,11 @@ static inline float f16_value_(unsigned short b) {
     memcpy(&h, &b, 2);
     return (float)h;
 }
-size_t pcc_tr2m_f16s_packed_floats(int Cin, int Cout) { return (size_t)(Cin / 16) * 27 * (Cout / 16) * 2 * 64 * 4 + PCC_TR2M_F16S_TAIL; }
+size_t pcc_tr2m_f16s_packed_floats(int Cin, int Cout) { return (size_t)(Cout / 16) * (Cin / 16) * (WG_BYTES / 4) + PCC_TR2M_F16S_TAIL; }
+// w_tr2g: [cin group][27][cout tile][64 lanes][4 floats] -> out: [cout tile][cin group][lane][27][4 h | 4 l] (+ 8 B pad per lane), tail[0] = su
 void pcc_tr2m_f16s_pack(int Cin, int Cout, const float* w_tr2g, float* out) {
-    const size_t nfrag = (size_t)(Cin / 16) * 27 * (Cout / 16);
+    const int NGi = Cin / 16, NCT = Cout / 16;
+    const size_t nfrag = (size_t)NGi * 27 * NCT;
     float wmax = 0.f;
     for (size_t i = 0; i < nfrag * 256; ++i) {
         const float v = fabsf(w_tr2g[i]);
@@ -388,33 +410,32 @@ void pcc_tr2m_f16s_pack(int Cin, int Cout, const float* w_tr2g, float* out) {
         se = se < -100 ? -100 : se > 100 ? 100 : se;
         su = ldexpf(1.f, se);
     }
+    memset(out, 0, pcc_tr2m_f16s_packed_floats(Cin, Cout) * sizeof(float));
     unsigned short* o = reinterpret_cast<unsigned short*>(out);
-    for (size_t f = 0; f < nfrag; ++f)
-        for (int lane = 0; lane < 64; ++lane) {
-            unsigned short h[4], l[4];
-            for (int c = 0; c < 4; ++c) {
-                const float x = w_tr2g[(f * 64 + lane) * 4 + c] * su;          // exact
-                h[c] = f16_bits_(x);
-                l[c] = f16_bits_(x - f16_value_(h[c]));                          // the difference is exact
-            }
-            unsigned short* a1 = o + ((f * 2 + 0) * 64 + lane) * 8;
-            unsigned short* a2 = o + ((f * 2 + 1) * 64 + lane) * 8;
-            for (int c = 0; c < 4; ++c) { a1[c] = h[c]; a1[4 + c] = h[c]; a2[c] = l[c]; a2[4 + c] = l[c]; }
-        }
-    float* tail = out + nfrag * 2 * 64 * 4;
-    for (int i = 0; i < PCC_TR2M_F16S_TAIL; ++i) tail[i] = 0.f;
-    tail[0] = su;
+    for (int g = 0; g < NGi; ++g)
+        for (int sq = 0; sq < 27; ++sq)
+            for (int ct = 0; ct < NCT; ++ct)
+                for (int lane = 0; lane < 64; ++lane) {
+                    unsigned short* d = o + ((size_t)(ct * NGi + g) * WG_BYTES + (size_t)lane * WL_LANE + (size_t)sq * 16) / 2;
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = w_tr2g[((((size_t)g * 27 + sq) * NCT + ct) * 64 + lane) * 4 + c] * su;          // exact
+                        d[c] = f16_bits_(x);
+                        d[4 + c] = f16_bits_(x - f16_value_(d[c]));                                                    // the difference is exact
+                    }
+                }
+    out[(size_t)NCT * NGi * (WG_BYTES / 4)] = su;
 }
 
-// the same layer conv_tr2m_bf16 covers: 32 -> 16 (its 108 KB of weight operands fit LDS beside the 30 KB tile); shape-only rule
-bool pcc_tr2m_f16s_covers(const pcc_conv_desc* d) { return pcc_tr2m_eligible(d) && d->Cin == 32 && d->Cout == 16; }
+// 32 -> 16 and 64 -> 32 on grids of 16-multiples (the layers conv_tr2m.hip marches); shape-only rule
+bool pcc_tr2m_f16s_covers(const pcc_conv_desc* d) { return pcc_tr2m_eligible(d); }
 
 int pcc_conv_tr2m_f16s(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, const float* w_f16s, const float* bias, float* out,
                        pcc_conv_ext* ext, hipStream_t st) {
     PCC_REQUIRE(pcc_tr2m_f16s_covers(d), "pcc_conv_tr2m_f16s: shape not covered");
+    const int NGi = d->Cin / 16;
     Tr2mArgs a;
     a.in = in; a.w = w_f16s; a.bias = bias; a.out = out;
-    a.wtail = w_f16s + (size_t)(d->Cin / 16) * 27 * (d->Cout / 16) * 2 * 64 * 4;
+    a.wtail = w_f16s + (size_t)(d->Cout / 16) * NGi * (WG_BYTES / 4);
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
     a.nty = d->H / 16; a.ntx = d->W / 16; a.nct = d->Cout / 16;
     a.flags = d->flags;
@@ -434,9 +455,10 @@ int pcc_conv_tr2m_f16s(pcc_ctx* ctx, const pcc_conv_desc* d, const float* in, co
     while (base * zs < ctx->num_cu && d->D % (zs * 2) == 0 && d->D / (zs * 2) >= 4) zs *= 2;
     a.zsplit = zs; a.zlen = d->D / zs;
     const int nwg = base * zs;
-    const int lds = W_BASE + 2 * 27 * 2048;
+    const int lds = W_BASE + ((NGi * WG_BYTES + 1023) / 1024) * 1024;
     typedef void (*kern_t)(Tr2mArgs, int);
-    const kern_t kern = (d->flags & PCC_CONV_RELU) ? (kern_t)conv_tr2m_f16s_kernel<2, true> : (kern_t)conv_tr2m_f16s_kernel<2, false>;
+    static const kern_t kerns[4] = {conv_tr2m_f16s_kernel<2, false>, conv_tr2m_f16s_kernel<2, true>, conv_tr2m_f16s_kernel<4, false>, conv_tr2m_f16s_kernel<4, true>};
+    const kern_t kern = kerns[(NGi == 4 ? 2 : 0) + ((d->flags & PCC_CONV_RELU) ? 1 : 0)];
     { const int rc = pcc_enable_big_lds((const void*)kern, lds); if (rc != PCC_OK) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds, st, a, nwg);
     PCC_CHECK_HIP(hipGetLastError());
