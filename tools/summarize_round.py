@@ -35,9 +35,9 @@ KERNELS = {
               2.0 * B * 16 ** 3 * 27 * 64 * 64 / 2, B * 16 ** 3 * 64 * 4 * 3, 'mfma'),
     'cin64_first': ('conv16_wino_f16s_kernel<false, false, 2, false>', 'the FIRST launch of the same layer (cin groups 0, 1 -> raw partial sums)',
               2.0 * B * 16 ** 3 * 27 * 64 * 64 / 2, B * 16 ** 3 * 64 * 4 * 2, 'mfma'),
-    'tr2m': ('conv_tr2m_f16s_kernel', 'Conv3DTranspose 32->16 k3 s2 32^3 -> 64^3, batch 32 (parity-decomposed, z-marching, two-piece fp16 operands, LDS-resident weights; round 5: conv_tr2m_bf16_kernel)',
+    'tr2m': ('conv_tr2m_f16s_kernel<2', 'Conv3DTranspose 32->16 k3 s2 32^3 -> 64^3, batch 32 (parity-decomposed, z-marching, two-piece fp16 operands, LDS-resident weights; round 5: conv_tr2m_bf16_kernel)',
              2.0 * B * 32 ** 3 * 27 * 32 * 16, B * (32 ** 3 * 32 + 64 ** 3 * 16) * 4, 'mfma'),
-    'tr2g': ('conv_tr2_split_kernel<64, 32', 'Conv3DTranspose 64->32 k3 s2 16^3 -> 32^3, batch 32 (parity-decomposed tiles, split-bf16 operands; round 3: conv_tr2g_kernel)',
+    'tr2g': ('conv_tr2m_f16s_kernel<4', 'Conv3DTranspose 64->32 k3 s2 16^3 -> 32^3, batch 32 (z-marching, two-piece fp16 operands, 110 KB of weight pieces LDS-resident; round 5: conv_tr2_split_kernel, 94 us)',
              2.0 * B * 16 ** 3 * 27 * 64 * 32, B * (16 ** 3 * 64 + 32 ** 3 * 32) * 4, 'mfma'),
     'fwd64_8': ('conv_k3s1_split_kernel<64, 1', 'Conv3D 64->64 k3 s1 @8^3, batch 32 (direct, split-bf16 operands, 8-wide rows; round 3: conv_fwd_kernel)',
                 2.0 * B * 8 ** 3 * 27 * 64 * 64, B * 8 ** 3 * 64 * 4 * 2, 'mfma'),
@@ -64,6 +64,9 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
                 for r in csv.DictReader(open(f)):
                     if frag in r['Kernel_Name']:
                         dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    if not dur:
+        print('no launch of', frag, 'in the counter pass of', key, file=sys.stderr)
+        continue
     tl = open(os.path.join(src, key, 'time.log')).read()
     m = re.search(r'min ([\d.]+) us median ([\d.]+) us', tl)
     t_min, t_med = (float(m.group(1)), float(m.group(2))) if m else (float('nan'),) * 2
@@ -71,7 +74,7 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
     # round 6: a stand-alone pcc_conv3d call of a two-piece fp16 layer runs pcc_block_amax in front of the kernel (inside pcc_network_forward the
     # producer records the maxima), and the 64-channel layer is two launches: bench_one's HIP events time the CALL.  The kernel's own
     # duration comes from the kernel trace of the counter pass instead (profiled clock: a few % slower than un-profiled)
-    if key in ('wino16', 'cin32', 'cin64', 'cin64_first', 'tr2m') and dur:
+    if key in ('wino16', 'cin32', 'cin64', 'cin64_first', 'tr2m', 'tr2g') and dur:
         sd = sorted(dur)
         t_min, t_med = sd[0], sd[len(sd) // 2]
     fetch = pmc.get('FETCH_SIZE', float('nan')) * 1024 * 2      # KB -> B, x2: gfx950 FETCH_SIZE counts 64 B per 128 B request (MI355X_MICROARCH.md)
@@ -86,7 +89,7 @@ for key, (frag, desc, alg_flops, alg_bytes, bound) in KERNELS.items():
            'call_us_bench_one_min_median': [t_call_min, t_call_med],
            'launch_us_in_counter_pass': sum(dur) / max(len(dur), 1),
            'algorithmic_flops_per_launch': alg_flops, 'executed_mfma_flops_per_launch': exec_flops,
-           'mfma_pipe': ('f16 (two-piece operands: 4x the multiply-adds of the fp32 kernel)' if key in ('wino16', 'cin32', 'cin64', 'cin64_first', 'tr2m') else 'bf16 (split operands: 6x the multiply-adds of the fp32 kernel)') if bf16 else 'fp32',
+           'mfma_pipe': ('f16 (two-piece operands: 4x the multiply-adds of the fp32 kernel)' if key in ('wino16', 'cin32', 'cin64', 'cin64_first', 'tr2m', 'tr2g') else 'bf16 (split operands: 6x the multiply-adds of the fp32 kernel)') if bf16 else 'fp32',
            'executed_tflops': exec_flops / (t_med * 1e-6) / 1e12, 'executed_frac_of_pipe_peak': exec_flops / (t_med * 1e-6) / 1e12 / (2500.0 if bf16 else PEAK_TF),
            'algorithmic_tflops': alg_flops / (t_med * 1e-6) / 1e12,
            'mfma_busy_frac_of_simd_cycles': pmc.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) / simd_cycles,
