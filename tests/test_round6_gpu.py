@@ -96,3 +96,34 @@ def test_recorded_block_maxima_equal_a_reduction_over_the_tensor():
     finally:
         del os.environ['PCC_LAYERWISE']
     assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize('cin,cout,D,N', [(32, 16, 16, 3), (64, 32, 8, 3)])
+def test_two_piece_fp16_marches_scale_per_block_and_match_the_oracle(cin, cout, D, N):
+    """conv_tr2m_f16s.hip (Conv3DTranspose k3 stride 2, /root/reference/src/model_transforms.py:78): within 8e-6 (1 + max |ref|) of the
+    fp64-accumulating oracle like the bf16 kernel it replaces; a block's bits do not depend on its neighbours in the launch; scaling one
+    block by a power of two scales its output bit for bit (bias-free); AUTO really takes the kernel."""
+    import ctypes
+    from pcc_geo_cnn_v2_amd import ops, _lib as L
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    ctx = _ctx()
+    rng = np.random.default_rng(11)
+    w = (rng.standard_normal((3, 3, 3, cout, cin)) / np.sqrt(27 * cin / 8)).astype(np.float32)
+    layer = ops.ConvLayer(w, None, 2, True, True)
+    H = 16
+    xn = rng.standard_normal((N, D, H, H, cin)).astype(np.float32)
+    x = torch.from_numpy(xn).to(ctx.device)
+    d = layer.desc(N, D, H, H, 0, L.PCC_IMPL_AUTO, 0, 0)
+    buf = ctypes.create_string_buffer(96)
+    L.check(L.lib().pcc_conv_kernel_family(ctx.handle, ctypes.byref(d), buf, 96), 'pcc_conv_kernel_family')
+    assert buf.value.decode().startswith('conv_tr2m_f16s')
+    base = ops.conv3d(ctx, x, layer)
+    ref = O.conv3d_transpose(xn[:1], w, None, 2, True)
+    assert np.abs(base[:1].cpu().numpy() - ref).max() <= 8e-6 * (1 + np.abs(ref).max())
+    y = x.clone()
+    y[0] *= 2.0 ** -40
+    y[N - 1] = 0
+    got = ops.conv3d(ctx, y, layer)
+    assert torch.equal(got[0], base[0] * 2.0 ** -40) and torch.count_nonzero(got[N - 1]) == 0 and torch.equal(got[1], base[1])
+    assert torch.equal(ops.conv3d(ctx, x[1:2].contiguous(), layer), base[1:2])
