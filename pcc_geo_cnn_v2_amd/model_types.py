@@ -471,6 +471,10 @@ class CompressionModel:
             chunk_, x_hat_ = item['chunk'], item['x_hat']
             n_m = len(max_deltas) * len(opt_metrics)
             host = [f.result() for f in item['futures']] if item['futures'] is not None else None
+            if host is not None and host and isinstance(host[0][1], tuple):      # 'tally_pruned' jobs: (tallies, (mean_tally, thresholds evaluated exactly))
+                self.search_trees_built = getattr(self, 'search_trees_built', 0) + sum(h[1][1] for h in host)
+                self.search_trees_total = getattr(self, 'search_trees_total', 0) + sum(len(h[0]) for h in host)
+                host = [(h[0], h[1][0]) for h in host]
             if item['d1'] is not None:
                 opt_metrics_ret, best_all = decide_from_tallies(chunk_, item['d1'], len(self.thresholds), resolution, opt_metrics, max_deltas, host,
                                                                 gpu_d2=item['gpu_d2'])
@@ -515,10 +519,18 @@ class CompressionModel:
                 gpu_d2 = want_d2 and on_gpu and d2_on_gpu(getattr(self, 'd2_search', None))          # nearest-index transforms, stated tie rule: opt-in (DESIGN_HISTORY.md 3.8)
                 strings = enc['finish']()
                 item = dict(chunk=chunk, x_hat=x_hat, futures=None, d1=None, gpu_d2=gpu_d2)
+                # (round 6) the host pool only builds the A->B trees of the thresholds that can still win a d2 metric: the workers get the
+                # GPU's exact D1 tallies as bounds (model_opt.host_threshold_stats_pruned); PCC_D2_NO_PRUNE=1: every threshold (A/B)
+                prune = on_gpu and want_d2 and not gpu_d2 and not os.environ.get('PCC_D2_NO_PRUNE')
+                if prune:
+                    item['d1'] = d1_tallies_gpu(ctx, chunk, x_hat, self.thresholds)
                 if (want_d2 and not gpu_d2) or not on_gpu:
                     xh = np.clip(x_hat.cpu().numpy(), 0.0, 1.0)
                     # blocks go over in their own dtype: the worker computes exactly what the in-process call would
-                    if on_gpu:
+                    if prune:
+                        jobs = [('tally_pruned', np.ascontiguousarray(chunk[j]), xh[j], self.thresholds, with_normals, item['d1'][j], resolution,
+                                 list(opt_metrics), list(max_deltas)) for j in range(len(chunk))]
+                    elif on_gpu:
                         jobs = [('tally', np.ascontiguousarray(chunk[j]), xh[j], self.thresholds, with_normals) for j in range(len(chunk))]
                     else:
                         jobs = [('decide', np.ascontiguousarray(chunk[j]), xh[j], self.thresholds, resolution, with_normals,
@@ -527,7 +539,7 @@ class CompressionModel:
                     self.last_host_job_kind = jobs[0][0] if jobs else None
                     pool = self._search_pool(len(blocks))
                     item['futures'] = [pool.submit(job) for job in jobs]
-                if on_gpu:
+                if on_gpu and item['d1'] is None:
                     item['d1'] = (d12_tallies_gpu if gpu_d2 else d1_tallies_gpu)(ctx, chunk, x_hat, self.thresholds)
                 pending.append(item)
                 if len(pending) > SEARCH_LAG:

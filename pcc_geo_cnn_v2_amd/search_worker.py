@@ -12,7 +12,7 @@ def main():
     wr = os.fdopen(os.dup(sys.stdout.fileno()), 'wb')
     os.dup2(sys.stderr.fileno(), sys.stdout.fileno())
     sys.stdout = sys.stderr
-    from pcc_geo_cnn_v2_amd.model_opt import compute_optimal_thresholds, host_threshold_stats
+    from pcc_geo_cnn_v2_amd.model_opt import compute_optimal_thresholds, host_threshold_stats, host_threshold_stats_pruned
     rd = sys.stdin.buffer
 
     def normals_of(block, with_normals):
@@ -28,6 +28,11 @@ def main():
             if kind == 'tally':
                 block, x_hat, thresholds, with_normals = args
                 out = ('ok',) + tuple(host_threshold_stats(block, x_hat, thresholds, normals_of(block, with_normals)))
+            elif kind == 'tally_pruned':
+                block, x_hat, thresholds, with_normals, d1_gpu, resolution, opt_metrics, max_deltas = args
+                tallies, mean_tally, kept = host_threshold_stats_pruned(block, x_hat, thresholds, normals_of(block, with_normals), d1_gpu, resolution,
+                                                                        opt_metrics, max_deltas)
+                out = ('ok', tallies, (mean_tally, kept))
             else:
                 block, x_hat, thresholds, resolution, with_normals, opt_metrics, max_deltas = args
                 names, best = compute_optimal_thresholds(block, x_hat, thresholds, resolution, normals=normals_of(block, with_normals),

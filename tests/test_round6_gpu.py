@@ -127,3 +127,53 @@ def test_two_piece_fp16_marches_scale_per_block_and_match_the_oracle(cin, cout, 
     got = ops.conv3d(ctx, y, layer)
     assert torch.equal(got[0], base[0] * 2.0 ** -40) and torch.count_nonzero(got[N - 1]) == 0 and torch.equal(got[1], base[1])
     assert torch.equal(ops.conv3d(ctx, x[1:2].contiguous(), layer), base[1:2])
+
+
+def test_bound_pruned_d2_search_takes_the_decisions_of_the_full_kdtree_search(monkeypatch):
+    """model_opt.host_threshold_stats_pruned (/root/reference/src/model_opt.py:33-73, src/utils/pc_metric.py:76-131): the
+    host pool builds the A->B KD-trees only for the thresholds whose lower bound (exact B->A side, zero A->B side) does not exceed the best
+    upper bound (A->B side <= max |n|^2 x the GPU's exact D1 sum).  Every decision -- d1 and d2, every max_delta -- must EQUAL the unpruned
+    search's on a voxelised shell with a plausible decoder output (ties at every level set), and most trees must really be skipped."""
+    import bench
+    from pcc_geo_cnn_v2_amd import ops
+    from pcc_geo_cnn_v2_amd.model_configs import ModelConfigType
+    from pcc_geo_cnn_v2_amd.utils.octree_coding import partition_octree
+    ctx = _ctx()
+    R, level, res = 1024, 4, 64
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal((1_200_000, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    rad = 200 + 6 * np.sin(9 * u[:, :1]) * np.cos(7 * u[:, 1:2]) + rng.normal(0, 0.6, (len(u), 1))
+    pts, first = np.unique(np.round(u * rad + np.array([512, 500, 520])).astype(np.int64), axis=0, return_index=True)
+    cloud = np.hstack([pts.astype(np.float64), u[first]])
+    blocks, _ = partition_octree(cloud, [0, 0, 0], [R] * 3, level)
+    blocks = blocks[::5]                                  # 40-odd blocks keep the unpruned run inside the test budget
+    model = ModelConfigType['c3p'].build(batch_size=16)
+    model.compress([1, 1, res, res, res])
+    model.set_weights(bench.synthetic_weights(model))
+    orig = model._encode_batch
+
+    def plausible(x):                                     # the recipe of the golden fixtures: blurred occupancy x 2.2 + noise, clipped
+        k = torch.exp(-torch.arange(-2, 3, device=x.device, dtype=torch.float32) ** 2 / (2 * 0.8 ** 2)); k /= k.sum()
+        v = x[:, None]
+        for ax in range(3):
+            shape = [1, 1, 1, 1, 1]; shape[2 + ax] = 5
+            pad = [0, 0, 0, 0, 0, 0]; pad[2 * (2 - ax)] = pad[2 * (2 - ax) + 1] = 2
+            v = torch.nn.functional.conv3d(torch.nn.functional.pad(v, pad), k.reshape(shape))
+        g = torch.Generator(device=x.device).manual_seed(int(x.sum().item()) & 0xffff)
+        return (v[:, 0] * 2.2 + 0.03 * torch.randn(x.shape, device=x.device, generator=g)).clamp_(0, 1).contiguous()
+
+    def enc(ctx_, x, debug=False, thr=None, slot=0):
+        e = orig(ctx_, x, debug, thr=thr, slot=slot)
+        e['x_hat'] = plausible(x)
+        return e
+    model._encode_batch = enc
+    mets, deltas = ['d1_mse', 'd2_mse', 'd2_sum_max'], [np.inf, 2.0]
+    monkeypatch.delenv('PCC_D2_NO_PRUNE', raising=False)
+    model.search_trees_built = model.search_trees_total = 0
+    pruned = model.encode_block_range(ctx, blocks, R, with_normals=True, opt_metrics=mets, max_deltas=deltas)[1]
+    built, total = model.search_trees_built, model.search_trees_total
+    monkeypatch.setenv('PCC_D2_NO_PRUNE', '1')
+    full = model.encode_block_range(ctx, blocks, R, with_normals=True, opt_metrics=mets, max_deltas=deltas)[1]
+    assert pruned == full
+    assert total > 0 and built < 0.5 * total, (built, total)
+    print(f'pruned d2 search: {built} of {total} A->B trees built ({100.0 * built / total:.1f} %), {len(blocks)} blocks, decisions equal')

@@ -48,3 +48,15 @@ for mets in (['d1_mse'], ['d1_mse', 'd2_mse']):
     differ = sum(a != b for a, b in zip(thr_new, thr_r3))
     print(f'{mets}: round 4 (all on the GPU, {jobs_new} host jobs) {t_new:.2f} s / cloud; round-3 dispatch (D2 on the host KD-tree pool) {t_r3:.2f} s / cloud, '
           f'{t_r3 / t_new:.1f}x; d1 decisions equal: {same_d1}; blocks whose d2 decision differs (tie rule): {differ} of {len(thr_new)}')
+
+# round 6: the default 'kdtree' search with and without the bound pruning of the host pool (model_opt.host_threshold_stats_pruned)
+model_opt.D2_SEARCH = 'kdtree'
+for tag, env in (('pruned (default)', None), ('PCC_D2_NO_PRUNE=1', '1')):
+    if env: os.environ['PCC_D2_NO_PRUNE'] = env
+    else: os.environ.pop('PCC_D2_NO_PRUNE', None)
+    model.search_trees_built = model.search_trees_total = 0
+    run(['d1_mse', 'd2_mse'])
+    t, thr_ = run(['d1_mse', 'd2_mse'])
+    print(f"kdtree search, {tag}: {t:.2f} s / cloud; A->B trees built {getattr(model, 'search_trees_built', 0)} of {getattr(model, 'search_trees_total', 0)} (two runs)")
+    globals()['thr_' + ('p' if env is None else 'f')] = thr_
+print('decisions equal:', thr_p == thr_f)

@@ -82,20 +82,26 @@ for kind in ('smooth', 'rough'):
     c = cloud(kind)
     blocks, binstr = partition_octree(c, [0, 0, 0], [R] * 3, level)
     res_by = {}
-    for mode in ('kdtree', 'gpu', 'kdtree', 'gpu'):          # (first pair = warm-up of pool and kernels)
-        model_opt.D2_SEARCH = mode
+    for mode in ('kdtree', 'gpu', 'kdtree', 'gpu', 'kdtree-unpruned'):          # (first pair = warm-up of pool and kernels)
+        model_opt.D2_SEARCH = mode.split('-')[0]
+        os.environ.pop('PCC_D2_NO_PRUNE', None)
+        if mode.endswith('unpruned'): os.environ['PCC_D2_NO_PRUNE'] = '1'
+        model.search_trees_built = model.search_trees_total = 0
         torch.cuda.synchronize(); t0 = time.perf_counter()
         data, meta, _ = model.compress_blocks(ctx, blocks, binstr, c, R, level, with_normals=True, opt_metrics=['d1_mse', 'd2_mse'],
                                               max_deltas=[np.inf], need_points=False)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        res_by[mode] = (dt, data, meta)
+        res_by[mode] = (dt, data, meta, model.search_trees_built, model.search_trees_total)
     thr_of = lambda data: [[t for _, t in d] for d in data]
     tk, tg = thr_of(res_by['kdtree'][1]), thr_of(res_by['gpu'][1])
-    for mode in ('kdtree', 'gpu'):
-        dt, data, meta = res_by[mode]
+    os.environ.pop('PCC_D2_NO_PRUNE', None)
+    assert thr_of(res_by['kdtree-unpruned'][1]) == tk, 'the bound-pruned search took a different decision'
+    for mode in ('kdtree-unpruned', 'kdtree', 'gpu'):
+        dt, data, meta, built, total = res_by[mode]
         m1, m2 = meta[0]['metrics'], meta[-1]['metrics']
         differ = sum(a != b for a, b in zip(tk[-1], tg[-1]))
         hist = np.bincount(np.clip(np.array(thr_of(data)[-1]), 0, 255) // 32, minlength=8)
-        print(f'| {kind} shell, {len(c)} points | {len(blocks)} | {mode} | {dt:.2f} | {differ if mode == "gpu" else "-"} | {m1["d1_psnr"]:.4f} | {m2.get("d2_psnr", float("nan")):.4f} (d2 indexes by 32s: {hist.tolist()}) |')
+        label = mode + (f' (bound-pruned: {built} of {total} A->B trees built)' if mode == 'kdtree' else '')
+        print(f'| {kind} shell, {len(c)} points | {len(blocks)} | {label} | {dt:.2f} | {differ if mode == "gpu" else "-"} | {m1["d1_psnr"]:.4f} | {m2.get("d2_psnr", float("nan")):.4f} (d2 indexes by 32s: {hist.tolist()}) |')
     print(f'| | | | | d1_mse decisions differing: {sum(a != b for a, b in zip(tk[0], tg[0]))}; bytes {sum(len(s) for ss, _ in res_by["kdtree"][1][0] for s in ss)} vs {sum(len(s) for ss, _ in res_by["gpu"][1][0] for s in ss)} | | |')
 model_opt.D2_SEARCH = None
