@@ -55,7 +55,8 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
 }
 // only VALU / SALU may cross: memory operations and MFMAs keep their written order (as PCC_PIN_MEM_MFMA in conv_mfma.hip)
 #define PCC_SPLIT_PIN() __builtin_amdgcn_sched_barrier(0x406)
-// timing probes (tools/build_variant.sh): 1 no weight loads in the tap loop, 2 no LDS operand reads in the tap loop, 4 no staging loads
+// timing probes (tools/build_variant.sh): 1 no weight loads in the tap loop, 2 no LDS operand reads in the tap loop, 4 no staging loads,
+// 8 (16x16x32 kernel only) MFMAs of tap 0 only.  64 -> 64 @8^3 x 32 alone, round 6: 23.8 us; 1: 19.0; 2: 22.5; 4: 22.5; 7: 17.5; 8: 8.5; 15: 7.9
 #ifndef PCC_SPLIT_PROBE
 #define PCC_SPLIT_PROBE 0
 #endif
@@ -120,7 +121,7 @@ struct SplitCfg {
     static constexpr int NV = LZ * LY * LX;             // staged voxels
     static constexpr int LDS_BYTES = LZ * LY * LXP * VS * 4;
     static constexpr int ITEMS = ((NV * 4 + NT - 1) / NT + 1) & ~1;      // (voxel, cin quad) items per thread, even: split two at a time
-    static constexpr int RING = 3;                      // weight ring depth (taps); 27 % RING == 0
+    static constexpr int RING = 3;                      // weight ring depth (taps); 27 % RING == 0 (9 on the 8^3 grids: measured equal, 250 VGPRs)
     static_assert(TY % (R * LPR) == 0 && NCT % CTW == 0 && 27 % RING == 0 && ITEMS <= 26 && (TXW == 16 || TXW == 8), "bad tile");
 };
 
@@ -230,18 +231,18 @@ conv_k3s1_split_kernel(SplitArgs a) {
             {
                 const int q = min(g * NTAP + ts + RING - 1, q_last);
 #pragma unroll
-                for (int ct = 0; ct < CTW; ++ct) {
+                for (int ct = 0; ct < CTW; ++ct) if (!(PCC_SPLIT_PROBE & 1)) {
                     wf1[(ts + RING - 1) % RING][ct] = buf_load4u(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 2048u);
                     wf2[(ts + RING - 1) % RING][ct] = buf_load4u(rw, wlane, (unsigned)(q * C::NCT + ct0 + ct) * 2048u + 1024u);
                 }
                 const int tn = (ts + 1 < NTAP) ? ts + 1 : ts;   // last tap: harmless re-read
                 const int toff = tap_off(tn / 9, (tn / 3) % 3, tn % 3);
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
+                for (int i = 0; i < R; ++i) if (!(PCC_SPLIT_PROBE & 2)) {
                     b1[(ts + 1) & 1][i] = *reinterpret_cast<const u32x4*>(lbase + toff + i * ROW_OFF);
                     b2[(ts + 1) & 1][i] = *reinterpret_cast<const u32x4*>(lbase + toff + i * ROW_OFF + 16);
                 }
-                if (ts < C::ITEMS) stg[ts] = buf_load4(rin, soff[ts], gnext);
+                if (ts < C::ITEMS && !(PCC_SPLIT_PROBE & 4)) stg[ts] = buf_load4(rin, soff[ts], gnext);
                 if (ts >= RES0 && ts < RES0 + NRES) {
                     const int i = (ts - RES0) / CTW, ct = (ts - RES0) % CTW;
                     const int gy = oy0 + ly0 + i * C::LPR, gx = ox0 + lx0;
@@ -260,6 +261,7 @@ conv_k3s1_split_kernel(SplitArgs a) {
                 for (int i = 0; i < R; ++i)
 #pragma unroll
                     for (int ct = 0; ct < CTW; ++ct)
+                        if (!(PCC_SPLIT_PROBE & 8) || ts == 0)
                         acc[i][ct] = mfma_bf16(tm == 2 ? wf2[ts % RING][ct] : wf1[ts % RING][ct], tm == 1 ? b2[ts & 1][i] : b1[ts & 1][i], acc[i][ct]);
             PCC_SPLIT_PIN();
         }
