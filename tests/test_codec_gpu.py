@@ -216,7 +216,7 @@ def test_adaptive_search_with_normals_dispatches_per_metric(ctx, monkeypatch):
     """VERDICT r02 item 5 / the reference's real experiment (ev_experiment.yml:47: opt_metrics ['d1_mse', 'd2_mse'] with
     normals), on the default dispatch (d2_* tallies from the host KD-tree pool = the reference's neighbour picks; the GPU D2 search
     is the opt-in of tests/test_threshold_search_gpu.py): d1_* decisions come from the GPU distance transforms even though normals are present, the
-    host pool receives 'tally' jobs only (KD-tree neighbour lists for the D2 columns), and every decision equals the in-process
+    host pool receives 'tally_pruned' jobs only (KD-tree neighbour lists for the D2 columns of the thresholds that can still win), and every decision equals the in-process
     host search (model_opt.compute_optimal_thresholds, itself pinned by the reference-generated tests/golden/model_opt_d2.npz).
     With d1 metrics only and normals in the input no host job is issued at all."""
     from pcc_geo_cnn_v2_amd import model_opt
@@ -237,7 +237,12 @@ def test_adaptive_search_with_normals_dispatches_per_metric(ctx, monkeypatch):
     strings, thr, cand, names, dbg = m.encode_block_range(ctx, blocks, 2 * res, with_normals=True, opt_metrics=mets, max_deltas=deltas,
                                                           debug=True)
     assert names == ['d1_mse_inf', 'd2_mse_inf', 'd1_mse_2.0', 'd2_mse_2.0']
-    assert m.last_host_job_kind == 'tally' and m.host_search_jobs == len(blocks)
+    # (round 6) the pool's jobs are the bound-pruned ones; PCC_D2_NO_PRUNE=1 gives the full per-threshold tallies: the same decisions
+    assert m.last_host_job_kind == 'tally_pruned' and m.host_search_jobs == len(blocks)
+    monkeypatch.setenv('PCC_D2_NO_PRUNE', '1')
+    thr_full = m.encode_block_range(ctx, blocks, 2 * res, with_normals=True, opt_metrics=mets, max_deltas=deltas)[1]
+    assert m.last_host_job_kind == 'tally' and thr_full == thr
+    monkeypatch.delenv('PCC_D2_NO_PRUNE')
     for j, blk in enumerate(blocks):
         xh = np.clip(dbg[j]['x_hat'][0, ..., 0], 0, 1)
         hn, hb = model_opt.compute_optimal_thresholds(blk, xh, m.thresholds, 2 * res, normals=blk[:, 3:6], opt_metrics=mets, max_deltas=deltas)
@@ -256,7 +261,7 @@ def test_adaptive_search_with_normals_dispatches_per_metric(ctx, monkeypatch):
     assert [t[0] for t in thr1] == [t[0] for t in thr] and [t[1] for t in thr1] == [t[2] for t in thr]
     # d2 only: the D2 tallies from the host pool, merged into the GPU's table
     _, thr2, _, names2, _ = m.encode_block_range(ctx, blocks, 2 * res, with_normals=True, opt_metrics=['d2_mse'], max_deltas=[np.inf])
-    assert m.last_host_job_kind == 'tally' and [t[0] for t in thr2] == [t[1] for t in thr]
+    assert m.last_host_job_kind == 'tally_pruned' and [t[0] for t in thr2] == [t[1] for t in thr]
     # the opt-in GPU D2 search: no host job at all, the same d1 decisions
     monkeypatch.setattr(model_opt, 'D2_SEARCH', 'gpu')
     before = m.host_search_jobs
