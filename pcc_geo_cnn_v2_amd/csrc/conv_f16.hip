@@ -45,6 +45,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// timing probes (tools/build_variant.sh, tools/r06_f16_probe.sh): 1 no MFMAs, 2 no plane loads, 4 no residual loads / stores, 8 no vmcnt wait / barrier
+// (2 | 4 leaves nothing observable: the compiler removes the kernel).  C = 16 @128^3 x 8 alone, round 6, us avg | min of 51 launches, with / without
+// residual: as shipped 364 | 305 / 317 | 256;  1: 297 | 293 / 210 | 200;  2: 308 | 242 / 254 | 223;  4: 102 | 99 / 102 | 99;  8: 357 | 320 / 305 | 240.
+// I.e. input side + matrix work 100 us (5.4 TB/s of reads), the output side (fp16 stores, residual rows) takes the launch to 200 - 300 us, the
+// MFMAs add 50 - 60 us on top of the memory-only time instead of hiding under it, and launches are bimodal (max 400 - 470 us).
+#ifndef PCC_F16_PROBE
+#define PCC_F16_PROBE 0
+#endif
+
 struct F16Args {
     const void* in;      // fp16 NDHWC
     const void* w;       // packed fp16 fragments (pcc_f16_pack)
@@ -198,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16_kernel(F16Args a, int nwg) {
         constexpr int RS = decltype(rs_tag)::value, PH = RS % 3;
         constexpr unsigned slotC = (unsigned)RS * K::PLANE_BYTES;                                  // plane s (read now)
         constexpr unsigned slotW = (unsigned)((RS + K::NRING - 1) % K::NRING) * K::PLANE_BYTES;    // plane s + NRING - 1 (requested now)
-        stage_plane(slotW, zb - 1 + s + K::NRING - 1);
+        if (!(PCC_F16_PROBE & 2)) stage_plane(slotW, zb - 1 + s + K::NRING - 1);
         const unsigned char* pl = smem + slotC + brow0;
 #pragma unroll
         for (int yi = 0; yi < K::R + 2; ++yi) {
@@ -216,12 +225,12 @@ __global__ void __launch_bounds__(256, 2) conv_f16_kernel(F16Args a, int nwg) {
                         const int as = (PH + 2 - kz) % 3;             // output plane zo = zi + 1 - kz
                         // the kz = 0 taps open a new output plane: its first MFMA starts from 0
                         const bool first = kz == 0 && f == 0 && ky == 0;
-                        acc[as][yo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[(kz * 3 + ky) * K::NF + f], B[f], first ? zero4 : acc[as][yo], 0, 0, 0);
+                        if (!(PCC_F16_PROBE & 1) || first) acc[as][yo] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[(kz * 3 + ky) * K::NF + f], B[f], first ? zero4 : acc[as][yo], 0, 0, 0);
                     }
         }
         // ---- the plane completed by the kz = 2 taps: zo = zb - 2 + s, acc slot PH
         const int zo = zb - 2 + s;
-        if (s >= 2) {
+        if (s >= 2 && !(PCC_F16_PROBE & 4)) {
             const __amdgpu_buffer_rsrc_t rout = raw ? make_rsrc(part_n + (size_t)zo * PLB, PLB) : make_rsrc(out_n + (size_t)zo * PLO, PLO);
 #pragma unroll
             for (int i = 0; i < K::R; ++i) {
@@ -256,21 +265,22 @@ __global__ void __launch_bounds__(256, 2) conv_f16_kernel(F16Args a, int nwg) {
                 }
             }
         }
-        load_res(PH, zo + 3);               // consumed three steps from now
+        if (!(PCC_F16_PROBE & 4)) load_res(PH, zo + 3);               // consumed three steps from now
         // vmcnt retires in order.  Plane s + 1, which the next step reads, was requested NRING - 2 steps ago (at the head of step
         // s - NRING + 2); everything issued in the NRING - 2 steps since may stay in flight across the barrier.  A step issues this
         // wave's plane loads (LASTN for the last wave), R residual (and R partial-sum) loads, and R stores once s >= 2 -- the
         // count must never exceed what was really issued, hence the two cases.
         constexpr int PER = (SUB ? 2 : 1) * K::R;
         const bool steady = s >= K::NRING - 1;          // steps s - NRING + 3 .. s all stored a plane
-        if (wave == 3) {
+        if (PCC_F16_PROBE & 8) {
+        } else if (wave == 3) {
             if (steady) __builtin_amdgcn_s_waitcnt(vmcnt_imm(imin((K::NRING - 2) * (K::LASTN + PER + K::R), 63)));
             else __builtin_amdgcn_s_waitcnt(vmcnt_imm(imin((K::NRING - 2) * (K::LASTN + PER), 63)));
         } else {
             if (steady) __builtin_amdgcn_s_waitcnt(vmcnt_imm(imin((K::NRING - 2) * (K::ITEMS + PER + K::R), 63)));
             else __builtin_amdgcn_s_waitcnt(vmcnt_imm(imin((K::NRING - 2) * (K::ITEMS + PER), 63)));
         }
-        __syncthreads();
+        if (!(PCC_F16_PROBE & 8)) __syncthreads();
     };
 
     for (int s = 0; s < nsteps; s += K::NRING) {
