@@ -103,6 +103,92 @@ __global__ void __launch_bounds__(256) k_edt_axis(const unsigned short* __restri
     out[base + i] = (unsigned short)min(best, (unsigned)kInf);
 }
 
+// ---- z and y passes in ONE kernel, linear time per line (round 6).  The two kernels above cost 0.51 of the 0.57 s a 190-block cloud spends in
+// the adaptive search: k_edt_z walks its lines with a stride of one line between lanes (165 GB/s), k_edt_axis visits ~40 candidates per
+// output element (its early exit needs best < d^2).  Here one wave owns the plane (b, t, x): (1) every line y of the plane becomes a bit
+// mask of its set voxels (level > t) in LDS -- the 1-D distance along z is then two bit scans, f(y', z) = dz(mask[y'], z)^2, never stored;
+// (2) lane z builds the lower envelope of the parabolas f(y', z) + (y - y')^2 over y' (Felzenszwalb & Huttenlocher's linear-time 1-D
+// transform with the stack in LDS, [entry][lane]) and evaluates it at every y.  All comparisons are exact integer cross-multiplications
+// (no intersection abscissa is ever divided out): the outputs are the same integers as k_edt_z + k_edt_axis, which stay as the fall-back
+// for shapes this kernel does not take (W % 16 != 0 or an edge > 128) and for the x pass of the originals' transform.
+constexpr int kBigDist = 1 << 20;
+template <int NW>
+__device__ __forceinline__ int zdist(const unsigned long long* m, int z) {
+    if constexpr (NW == 1) {
+        const unsigned long long lo = m[0] & (~0ull >> (63 - z)), hi = m[0] >> z;
+        const int dl = lo ? z - (63 - __clzll((long long)lo)) : kBigDist, dr = hi ? __ffsll((long long)hi) - 1 : kBigDist;
+        return dl < dr ? dl : dr;
+    } else {
+        const int w = z >> 6, bit = z & 63;
+        const unsigned long long lo = m[w] & (~0ull >> (63 - bit)), hi = m[w] >> bit;
+        int dl = kBigDist, dr = kBigDist;
+        if (lo) dl = bit - (63 - __clzll((long long)lo));
+        else if (w == 1 && m[0]) dl = z - (63 - __clzll((long long)m[0]));
+        if (hi) dr = __ffsll((long long)hi) - 1;
+        else if (w == 0 && m[1]) dr = 64 + __ffsll((long long)m[1]) - 1 - z;
+        return dl < dr ? dl : dr;
+    }
+}
+template <int NW, int HM>      // NW = 64-bit words per line (W <= 64 NW), HM = stack depth (H <= HM): 12.5 KB of LDS per wave at 64^3, 25 KB at 128^3
+__global__ void __launch_bounds__(64) k_edt_zy(const unsigned char* __restrict__ lev, const int* __restrict__ tcount, int tmax, int t0,
+                                               int D, int H, int W, unsigned short* __restrict__ out) {
+    const int x = blockIdx.x, tl = blockIdx.y, b = blockIdx.z, t = t0 + tl;
+    if (t >= tcount[b]) return;
+    __shared__ unsigned long long mask[HM][NW];
+    __shared__ unsigned char sv[HM][64];         // envelope stack of lane z: positions y' ...
+    __shared__ unsigned short sF[HM][64];        // ... and F = f + y'^2 (<= 2 * 127^2)
+    const int lane = threadIdx.x;
+    for (int y = lane; y < H; y += 64) {
+        const unsigned char* l = lev + (((size_t)b * D + x) * H + y) * W;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            unsigned long long m = 0;
+            for (int j = 0; j < 64 && w * 64 + j < W; j += 16) {
+                const uint4 q = *reinterpret_cast<const uint4*>(l + w * 64 + j);
+                const unsigned qs[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if ((int)((qs[u] >> (8 * c)) & 255u) > t) m |= 1ull << (j + 4 * u + c);
+            }
+            mask[y][w] = m;
+        }
+    }
+    __syncthreads();
+    for (int z = lane; z < W; z += 64) {
+        int k = -1;
+        for (int q = 0; q < H; ++q) {
+            const int dz = zdist<NW>(mask[q], z);
+            if (dz >= kBigDist) continue;                    // line q has no set voxel
+            const int Fq = dz * dz + q * q;
+            // the top entry leaves when its segment is empty: s(v[k-1], v[k]) >= s(v[k], q), cross-multiplied (all differences of positions > 0)
+            while (k >= 1) {
+                const int vk = sv[k][lane], Fk = sF[k][lane], vj = sv[k - 1][lane], Fj = sF[k - 1][lane];
+                if ((Fk - Fj) * (q - vk) >= (Fq - Fk) * (vk - vj)) --k; else break;
+            }
+            ++k;
+            sv[k][lane] = (unsigned char)q;
+            sF[k][lane] = (unsigned short)Fq;
+        }
+        unsigned short* o = out + ((((size_t)b * tmax + tl) * D + x) * H) * W + z;
+        if (k < 0) {
+            for (int p = 0; p < H; ++p) o[(size_t)p * W] = kInf;
+            continue;
+        }
+        int j = 0, vj = sv[0][lane], Fj = sF[0][lane];
+        for (int p = 0; p < H; ++p) {
+            while (j < k) {                                  // the next parabola takes over where it is at least as low
+                const int vn = sv[j + 1][lane], Fn = sF[j + 1][lane];
+                if (Fn - 2 * p * vn <= Fj - 2 * p * vj) { ++j; vj = vn; Fj = Fn; } else break;
+            }
+            const int val = Fj - 2 * p * vj + p * p;
+            o[(size_t)p * W] = (unsigned short)(val < (int)kInf ? val : (int)kInf);
+        }
+    }
+}
+static bool edt_zy_takes(int D, int H, int W) { return W % 16 == 0 && W <= 128 && H <= 128 && D >= 1; }
+
 // last pass (along x = the slowest axis) evaluated only at the points of A: S_AB[b][t] += min_x' (x_a-x')^2 + g[x'][y_a][z_a]
 __global__ void __launch_bounds__(256) k_edt_points(const unsigned short* __restrict__ g, const int* __restrict__ tcount,
                                                     int tmax, int t0, const int* __restrict__ pts, const int* __restrict__ block_of,
@@ -219,8 +305,17 @@ PCC_API int pcc_d1_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, 
         hipLaunchKernelGGL(k_occupancy, dim3(pblocks), dim3(256), 0, st, pts, block_of, (long long)npts, D, H, W, occ);
     }
     hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, one, 1, B);
-    hipLaunchKernelGGL(k_edt_z, dim3((lines + 255) / 256, 1, B), dim3(256), 0, st, occ, one, 1, 0, lines, W, ea0);
-    hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, 1, B), dim3(256), 0, st, ea0, one, 1, 0, nvox, H, W, ea1);
+    const bool fused = edt_zy_takes(D, H, W) && !getenv("PCC_EDT_OLD");
+    auto launch_zy = [&](const unsigned char* levels, const int* counts, int tmax_, int t0_, int nt_, unsigned short* dst) {
+        if (W <= 64 && H <= 64) hipLaunchKernelGGL((k_edt_zy<1, 64>), dim3(D, nt_, B), dim3(64), 0, st, levels, counts, tmax_, t0_, D, H, W, dst);
+        else if (W <= 64) hipLaunchKernelGGL((k_edt_zy<1, 128>), dim3(D, nt_, B), dim3(64), 0, st, levels, counts, tmax_, t0_, D, H, W, dst);
+        else hipLaunchKernelGGL((k_edt_zy<2, 128>), dim3(D, nt_, B), dim3(64), 0, st, levels, counts, tmax_, t0_, D, H, W, dst);
+    };
+    if (fused) launch_zy(occ, one, 1, 0, 1, ea1);
+    else {
+        hipLaunchKernelGGL(k_edt_z, dim3((lines + 255) / 256, 1, B), dim3(256), 0, st, occ, one, 1, 0, lines, W, ea0);
+        hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, 1, B), dim3(256), 0, st, ea0, one, 1, 0, nvox, H, W, ea1);
+    }
     hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, 1, B), dim3(256), 0, st, ea1, one, 1, 0, nvox, D, H * W, ea0);
     hipLaunchKernelGGL(k_level_hist, dim3(64, B), dim3(256), 0, st, lev, ea0, nvox, (unsigned long long*)hsum,
                        (unsigned long long*)hcnt);
@@ -228,8 +323,11 @@ PCC_API int pcc_d1_threshold_stats(pcc_ctx* ctx, const float* x_hat, int32_t B, 
     //      in chunks of TC thresholds (workspace bound); chunks beyond every block's tcount exit at once
     for (int t0 = 0; t0 < nthr; t0 += TC) {
         const int nt = nthr - t0 < TC ? nthr - t0 : TC;
-        hipLaunchKernelGGL(k_edt_z, dim3((lines + 255) / 256, nt, B), dim3(256), 0, st, lev, tcount, TC, t0, lines, W, g0);
-        hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, nt, B), dim3(256), 0, st, g0, tcount, TC, t0, nvox, H, W, g1);
+        if (fused) launch_zy(lev, tcount, TC, t0, nt, g1);
+        else {
+            hipLaunchKernelGGL(k_edt_z, dim3((lines + 255) / 256, nt, B), dim3(256), 0, st, lev, tcount, TC, t0, lines, W, g0);
+            hipLaunchKernelGGL(k_edt_axis, dim3(vox_blocks, nt, B), dim3(256), 0, st, g0, tcount, TC, t0, nvox, H, W, g1);
+        }
         if (npts > 0) {
             const unsigned pblocks = (unsigned)((npts + 255) / 256);
             hipLaunchKernelGGL(k_edt_points, dim3(pblocks, nt), dim3(256), 0, st, g1, tcount, TC, t0, pts, block_of,
