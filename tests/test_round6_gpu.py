@@ -177,3 +177,33 @@ def test_bound_pruned_d2_search_takes_the_decisions_of_the_full_kdtree_search(mo
     assert pruned == full
     assert total > 0 and built < 0.5 * total, (built, total)
     print(f'pruned d2 search: {built} of {total} A->B trees built ({100.0 * built / total:.1f} %), {len(blocks)} blocks, decisions equal')
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 64, 64), (2, 128, 128, 128), (2, 32, 48, 80), (2, 16, 24, 40), (1, 8, 128, 64)])
+def test_fused_linear_time_distance_passes_give_the_integers_of_the_two_kernel_form(shape, monkeypatch):
+    """threshold_search.hip k_edt_zy (round 6): the z and y passes of the squared Euclidean distance transform of every level set in one
+    kernel -- bit masks for the z distances, a lower envelope of parabolas along y with exact integer cross-multiplied comparisons --
+    must give the sums of the two brute-force kernels (PCC_EDT_OLD=1) bit for bit: sparse and dense level sets, empty lines and planes,
+    64^3 and 128^3 blocks (one and two mask words), edges that are not powers of two, and a shape the fused kernel does not take
+    (W % 16 != 0: both runs then use the old kernels).  The search these sums feed restates /root/reference/src/model_opt.py:33-73."""
+    from pcc_geo_cnn_v2_amd import ops
+    ctx = _ctx()
+    B, D, H, W = shape
+    rng = np.random.default_rng(B * 1000 + W)
+    x = rng.random((B, D, H, W), dtype=np.float32) ** 6                   # few voxels above the high thresholds
+    x[0, : D // 2] = 0.0                                                  # empty planes and lines
+    x[-1, :, :, : W // 3] *= 0.01
+    pts, bof = [], []
+    for b in range(B):
+        p = np.argwhere(rng.random((D, H, W)) < 0.02).astype(np.int32)
+        pts.append(p); bof.append(np.full(len(p), b, np.int32))
+    pts, bof = np.ascontiguousarray(np.vstack(pts)), np.concatenate(bof)          # (np.argwhere hands out a transposed view)
+    thr = torch.from_numpy(np.linspace(0, 1.0, 256).astype(np.float32)).to(ctx.device)
+    args = (ctx, torch.from_numpy(x).to(ctx.device), thr, torch.from_numpy(pts).to(ctx.device), torch.from_numpy(bof).to(ctx.device))
+    monkeypatch.delenv('PCC_EDT_OLD', raising=False)
+    new = ops.d1_threshold_stats(*args)
+    monkeypatch.setenv('PCC_EDT_OLD', '1')
+    old = ops.d1_threshold_stats(*args)
+    for a, b in zip(new, old):
+        assert np.array_equal(a, b)
+    assert new[3].max() > 200 and new[0].any()
