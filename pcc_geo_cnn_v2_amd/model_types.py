@@ -71,7 +71,7 @@ def rank_candidates(names, cand_metrics, opt_groups=('d1', 'd2')):
 
 
 def select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics, points, resolution, with_normals,
-                               opt_groups=('d1', 'd2')):
+                               opt_groups=('d1', 'd2'), tree=None):
     """Per optimisation group, which candidate reconstruction of the whole cloud to keep (the reference's function of the same
     name, model_types.py:128-176; results pinned by tests/golden/select_best.npz).  x_hat_list[m] = the decoded blocks of
     candidate m (block-local coordinates).  Returns one dict per non-empty group: 'idx', 'metrics', 'x_hat_list',
@@ -82,8 +82,9 @@ def select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics, points, r
     placed = {m: departition_octree(x_hat_list[m], binstr, [0, 0, 0], [resolution] * 3, level) for m in grouped}
     clouds = {m: np.vstack(placed[m]) for m in grouped}
     original = points[:, :3]
+    # `tree`: the KD-tree over the original points when the caller built it meanwhile (compress_blocks: beside the block loop)
     scored = cloud_metrics_batch(original, [clouds[m] for m in grouped], resolution - 1, get_normals_if(points, with_normals),
-                                 cKDTree(original))
+                                 tree if tree is not None else cKDTree(original))
     cand_metrics = [None] * len(opt_metrics)
     for m, met in zip(grouped, scored):
         cand_metrics[m] = met
@@ -559,13 +560,21 @@ class CompressionModel:
         decoded candidate point lists to rank 0 (they are only needed for --dec_files / --debug)."""
         from . import sharding
         rank, world = sharding.world_info()
+        # The KD-tree over the ORIGINAL cloud (the whole-cloud metrics of every candidate query it: pc_metric.py:80) does not depend on the
+        # encode: it is built on a helper thread while the GPU codes the blocks (0.11 s of a 614 k-point cloud's 0.30 s; scipy builds
+        # without the GIL).  Same constructor call as before: the same tree, the same neighbour picks.
+        self._tree_future = self._helper_thread('tree').submit(cKDTree, points[:, :3]) if len(points) else None
         if world == 1:
-            strings_list, threshold_list, x_hat_list, opt_metrics_ret, debug_t_list = self.encode_block_range(
-                sess, blocks, resolution, with_normals, opt_metrics, max_deltas, fixed_threshold, debug)
+            try:
+                strings_list, threshold_list, x_hat_list, opt_metrics_ret, debug_t_list = self.encode_block_range(
+                    sess, blocks, resolution, with_normals, opt_metrics, max_deltas, fixed_threshold, debug)
+            finally:
+                tree = self._tree_future.result() if self._tree_future is not None else None
+                self._tree_future = None
             # block -> opt metric to opt metric -> block
             threshold_list = list(zip(*threshold_list))
             x_hat_list = list(zip(*x_hat_list))
-            metadata = select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics_ret, points, resolution, with_normals)
+            metadata = select_best_per_opt_metric(binstr, x_hat_list, level, opt_metrics_ret, points, resolution, with_normals, tree=tree)
             data_list = [list(zip(strings_list, threshold_list[x['idx']])) for x in metadata]
             return data_list, metadata, debug_t_list
         return self._compress_blocks_sharded(sess, blocks, binstr, points, resolution, level, with_normals, opt_metrics,
@@ -577,8 +586,14 @@ class CompressionModel:
         from .utils.octree_coding import block_origins
         rank, world = sharding.world_info()
         lo, hi = sharding.shard_range(len(blocks), rank, world)
-        strings_l, thr_l, xhat_l, names, debug_t_list = self.encode_block_range(
-            sess, blocks[lo:hi], resolution, with_normals, opt_metrics, max_deltas, fixed_threshold, debug)
+        try:
+            strings_l, thr_l, xhat_l, names, debug_t_list = self.encode_block_range(
+                sess, blocks[lo:hi], resolution, with_normals, opt_metrics, max_deltas, fixed_threshold, debug)
+        finally:
+            fut, self._tree_future = getattr(self, '_tree_future', None), None
+            tree_a = fut.result() if fut is not None else None
+        if tree_a is None:
+            tree_a = cKDTree(points[:, :3])
         n_str = 1 if isinstance(self, CompressionModelV1) else 2
         n_m = len(max_deltas) * len(opt_metrics)
         if names is None or not len(blocks[lo:hi]):
@@ -605,7 +620,7 @@ class CompressionModel:
             # TWO collectives per cloud: (1) ONE all_gather of the rows with the MIN keys of all candidates riding as extra
             # rows (sharding.PiggybackGroup: every rank takes the MIN itself), (2) ONE all_gather of bytes: strings + the partial tallies
             grp = sharding.PiggybackGroup(rows, per_rank)
-            part_tallies, have = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, cKDTree(p1), grp, partial=True)
+            part_tallies, have = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, tree_a, grp, partial=True)
             table = grp.table
             tb = np.ascontiguousarray(part_tallies, np.float64).tobytes()
             payloads = sharding.all_gather_bytes(my_strings + tb, counts=[int(table[first[r]:first[r + 1], :n_str].sum()) + len(tb) for r in range(world)])
@@ -617,7 +632,7 @@ class CompressionModel:
             # a cloud whose keys (8 B per original point and candidate) are too many to move `world` times: THREE collectives -- (1) ONE
             # all_reduce(MIN) of the keys, (2) ONE all_gather of the rows + T rows with the bit patterns of the partial tallies (summed in
             # rank order), (3) ONE padded uint8 gather of the strings to rank 0
-            part_tallies, have = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, cKDTree(p1), sharding.RankGroup(), partial=True)
+            part_tallies, have = cloud_metrics_batch(p1, cand_global, resolution - 1, p1_n, tree_a, sharding.RankGroup(), partial=True)
             T = -(-part_tallies.size // width)
             send = np.zeros((hi - lo + T, width), np.int64)
             send[:hi - lo] = rows
