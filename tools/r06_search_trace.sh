@@ -25,5 +25,5 @@ for rep in range(2):
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o t -- python $OUT/run.py 2>&1 | grep "encode_block_range"
 f=$(find $OUT/t -name "t_kernel_stats.csv" | head -1)
-head -14 $f | cut -c1-150
+head -24 $f | cut -c1-110,150-230
 rm -rf $OUT/t
